@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the body->hand hot path on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the fused four-layer kernel (ConvModel.forward,
+body2hand/src/models/HandPoseModels.py:40-64 of the reference) over this rank's
+resident shard of a synthetic keypoint stream.  Workload: BASELINE.json config 3
+(bf16 MFMA path, T = 200) fed as a sustained stream -- 65 536 sequences x 200
+frames per GPU per step (256 batches of config 3's batch=256; 3.46 GB of HBM
+traffic per step, beyond the 256 MiB Infinity Cache), sequence-sharded across
+ranks with no data-path collective (weak scaling).  The metric "hand-crops/sec"
+of BASELINE.json is reported as frames/s: the reference has no image crops, one
+"crop" = one frame of 12x2 body keypoints in -> 21x2 hand keypoints out
+(SURVEY.md section 0).
+
+Rank 0 prints ONE JSON line (see the repo's task contract), with two extra
+objects: "roofline" (HIP-event launch time of the kernel vs HBM peak) and
+"cpu_baseline" (the reference's CPU execution -- four torch Conv1d calls --
+timed on this box's host cores; reported only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_FRAME = 264      # 24 fp32 in + 42 fp32 out; weights 76 KB amortised
+FLOP_PER_FRAME = 37800     # 18 900 MAC
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32_mfma": 157.3, "f32_valu": 157.3, "fp32": 157.3}
+DTYPE = {"bf16": "bf16", "f16": "f16", "f32_mfma": "f32", "f32_valu": "f32", "fp32": "f32"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seqs", type=int, default=65536, help="sequences per GPU per step")
+    ap.add_argument("--frames", type=int, default=200, help="T, frames per sequence (--max-frames default, run.py:28)")
+    ap.add_argument("--precision", default="bf16", choices=sorted(MFMA_PEAK_TFLOPS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--gather", action="store_true",
+                    help="also time handing a config-4 stream (2000 seq) back to rank 0 (reported aside)")
+    return ap.parse_args()
+
+
+def cpu_baseline(model, seconds):
+    """Reference CPU path (torch Conv1d x4 == oracle.torch_port) on the host cores,
+    bounded sample: config 2/3-sized batches (256 x 200 frames) repeated for ~`seconds`."""
+    import numpy as np
+    import torch
+
+    import oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    port = oracle.TorchPort(state, pos_emb=False)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((256, 200, 12, 2), generator=g) - 0.5
+    for _ in range(3):
+        y_cpu = port(x)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        y_cpu = port(x)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 20000:
+            break
+    fps = n * 256 * 200 / el
+    # the same sample through the HIP path, checked against the CPU result
+    import torch as _t
+    with _t.no_grad():
+        y_gpu = model(x.to(next(model.parameters()).device)).cpu()
+    err = float((y_gpu - y_cpu.contiguous()).abs().max())
+    return {"value": fps, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"(256,200,12,2) U[-0.5,0.5] x {n} passes in {el:.1f} s, torch {torch.__version__} "
+                      f"Conv1d x4 fp32 (oracle/torch_port.py)",
+            "gflops": fps * FLOP_PER_FRAME / 1e9, "gpu_max_abs_err_on_sample": err}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import hand_pose_sl_amd as hps
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU path in the product)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    S, T = args.seqs, args.frames
+    torch.manual_seed(0)
+    model = hps.ConvModel(30, "ReLU", False, precision=args.precision).to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    # synthetic stream shard, resident in HBM before the timed region
+    x = torch.empty((S, T, 12, 2), dtype=torch.float32, device=dev)
+    chunk = 4096
+    for i in range(0, S, chunk):
+        n = min(chunk, S - i)
+        x[i:i + n] = (torch.rand((n, T, 12, 2), generator=g) - 0.5).to(dev)
+    y = torch.empty((S, T, 21, 2), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    import ctypes
+
+    from hand_pose_sl_amd import _lib
+    lib = model._ensure_handle()
+    kern = _lib.KERNELS[args.precision]
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    xp, yp = ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr())
+
+    def step():
+        _lib.check(lib.b2h_forward(model._handle, xp, yp, S, T, kern, st))
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    frames_total = S * T * world * args.steps
+    value = frames_total / el
+    out = {
+        "metric": "hand-crops/sec (1 crop = 1 frame: 12x2 body kpts -> 21x2 hand kpts; the reference has no 256x256 images)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
+        "config": {"workload": f"BASELINE config 3 stream: ConvModel(30,'ReLU',pos_emb=False) {args.precision} "
+                               f"path, {S} seq x {T} frames per GPU per step, inputs resident in HBM, "
+                               f"sequence-sharded, no data-path collective",
+                   "seqs_per_gpu": S, "frames_per_seq": T, "conv_channels": 30, "kernel": model.kernel_name(),
+                   "parallelism": f"seq-shard x{world}"},
+    }
+
+    if rank == 0:
+        # roofline of the dominant (only) kernel: HIP events on the launch stream
+        iters = max(5, min(args.steps, 50))
+        ms = model.time_forward(x, y, iters)
+        alg_bytes = S * T * BYTES_PER_FRAME
+        gbs = alg_bytes / (ms * 1e-3) / 1e9
+        tfl = S * T * FLOP_PER_FRAME / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": model.kernel_name(), "launch_ms": ms, "launches_timed": iters,
+                           "bytes_per_launch": alg_bytes,
+                           "mfma_tflops": tfl, "mfma_peak_tflops": MFMA_PEAK_TFLOPS[args.precision],
+                           "mfma_frac": tfl / MFMA_PEAK_TFLOPS[args.precision]}
+        traffic = os.environ.get("B2H_PMC_TRAFFIC_BYTES")  # filled from profiles/ when re-run after a --pmc pass
+        if traffic:
+            out["roofline"]["traffic"] = float(traffic)
+
+    if args.gather and world >= 1:
+        from hand_pose_sl_amd.stream import ShardedStream, shard_bounds
+        n_seq = 2000
+        lo, hi = shard_bounds(n_seq, rank, world)
+        stream = ShardedStream(model)
+        xs = x[: hi - lo]
+        for _ in range(2):
+            stream.run(xs, n_seq, gather=True)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            stream.run(xs, n_seq, gather=True)
+        barrier()
+        eg = (time.perf_counter() - t0) / reps
+        if rank == 0:
+            out["gather"] = {"workload": "config 4: 2000 seq x 200 frames sharded, keypoints handed back to rank 0",
+                             "ms": eg * 1e3, "frames_per_s": n_seq * T / eg}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, args.cpu_seconds)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,9 @@
+"""hand_pose_sl_amd -- MI355X-native body->hand keypoint inference path.
+
+A from-scratch gfx950 implementation of the one convolutional model of
+benoriol/hand_pose_sl (`ConvModel`, body2hand/src/models/HandPoseModels.py:17-64)
+behind the reference's own call surface.  See DESIGN.md and include/b2h.h.
+"""
+from .conv_model import ConvModel, LinearPositionalEmbedding, target_transform  # noqa: F401
+
+__all__ = ["ConvModel", "LinearPositionalEmbedding", "target_transform"]

@@ -1,0 +1,179 @@
+"""Drop-in mirror of the reference's `ConvModel` (body2hand/src/models/
+HandPoseModels.py:17-64) whose forward runs on libb2h's gfx950 kernels.
+
+Same constructor `ConvModel(conv_channels, activation, pos_emb)`, same
+`state_dict` keys `conv{1..4}.{weight,bias}` (so `load_state_dict(torch.load(p))`
+from infer_utterance.py:109 works), same call `model(x)` with x float32
+(B, T, 12, 2) -> float32 (B, T, 21, 2).  The `nn.Conv1d` children are parameter
+containers only -- constructing them in the reference's order also makes a
+seeded default init identical to the reference's -- their forward is never
+called: the four layers run fused in one HIP kernel through the C ABI.
+
+Inference only (the north-star path).  Calling the module with autograd enabled
+on parameters that require grad raises, it never silently runs PyTorch ops.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class LinearPositionalEmbedding(nn.Module):
+    """Marker for `pos_emb=True` (HandPoseModels.py:66-84): channel t/100, T == 100.
+    The embedding itself is generated inside the kernel."""
+
+    def __init__(self, max_len=100):
+        super().__init__()
+        self.max_len = max_len
+
+
+class ConvModel(nn.Module):
+    def __init__(self, conv_channels, activation, pos_emb, precision="fp32"):
+        super().__init__()
+        if pos_emb:
+            self.pos_emb = LinearPositionalEmbedding(max_len=100)
+            self.conv1 = nn.Conv1d(12 * 2 + 1, conv_channels, kernel_size=5, padding=2)
+        else:
+            self.pos_emb = None
+            self.conv1 = nn.Conv1d(12 * 2, conv_channels, kernel_size=5, padding=2)
+        self.conv2 = nn.Conv1d(conv_channels, conv_channels, kernel_size=5, padding=2)
+        self.conv3 = nn.Conv1d(conv_channels, conv_channels, kernel_size=5, padding=2)
+        self.conv4 = nn.Conv1d(conv_channels, 2 * 21, kernel_size=5, padding=2)
+        if activation != "ReLU":
+            raise ValueError()  # HandPoseModels.py:34-37
+        self.activation = nn.ReLU()
+        self.conv_channels = int(conv_channels)
+        self.precision = precision
+        if precision not in _lib.KERNELS:
+            raise ValueError(f"precision must be one of {sorted(_lib.KERNELS)}")
+        self._handle = None
+        self._packed_key = None
+
+    # ---- native handle -----------------------------------------------------
+    def _params(self):
+        return [self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                self.conv3.weight, self.conv3.bias, self.conv4.weight, self.conv4.bias]
+
+    def _device(self):
+        return self.conv1.weight.device
+
+    def _ensure_handle(self):
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("hand_pose_sl_amd.ConvModel runs on an MI355X only: call "
+                               "model.to('cuda') first (there is no CPU path in the product)")
+        lib = _lib.load()
+        key = (dev.index,) + tuple((p.data_ptr(), p._version) for p in self._params())
+        if self._handle is not None and key == self._packed_key:
+            return lib
+        with torch.cuda.device(dev):
+            if self._handle is None or self._packed_key[0] != dev.index:
+                self._free()
+                h = ctypes.c_void_p()
+                _lib.check(lib.b2h_create(self.conv_channels, b"ReLU", int(self.pos_emb is not None),
+                                          ctypes.byref(h)))
+                self._handle = h
+            ps = [p.detach().to(torch.float32).contiguous() for p in self._params()]
+            torch.cuda.current_stream(dev).synchronize()
+            _lib.check(lib.b2h_load_weights(self._handle, *[ctypes.c_void_p(p.data_ptr()) for p in ps], 1))
+        self._packed_key = key
+        return lib
+
+    def _free(self):
+        if self.__dict__.get("_handle") is not None:
+            try:
+                _lib.load().b2h_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+            self._packed_key = None
+
+    def __del__(self):
+        self._free()
+
+    # ---- forward -------------------------------------------------------------
+    def kernel_name(self, precision=None):
+        lib = self._ensure_handle()
+        return lib.b2h_kernel_name(self._handle, _lib.KERNELS[precision or self.precision]).decode()
+
+    def _check_input(self, inp):
+        if inp.dim() != 4 or inp.shape[2] != 12 or inp.shape[3] != 2:
+            raise RuntimeError(f"expected input of shape (B, T, 12, 2), got {tuple(inp.shape)}")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise RuntimeError("hand_pose_sl_amd.ConvModel is inference-only: call model.eval() and "
+                               "wrap the call in torch.no_grad() as steps/traintest.py:350-351 does")
+        dev = self._device()
+        # traintest.py:354-358 passes batch["body_kp"], which the loop never moved to the device
+        x = inp.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+        return x
+
+    def forward(self, inp):
+        lib = self._ensure_handle()
+        x = self._check_input(inp)
+        B, T = x.shape[0], x.shape[1]
+        y = torch.empty((B, T, 21, 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            st = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(lib.b2h_forward(self._handle, ctypes.c_void_p(x.data_ptr()),
+                                       ctypes.c_void_p(y.data_ptr()), B, T,
+                                       _lib.KERNELS[self.precision], ctypes.c_void_p(st)))
+        return y
+
+    def forward_fused(self, body, n_frames=None, dif_encoding=True, normalize=True, denormalize=True,
+                      mask_tail=False, factor=1280.0):
+        """Raw-pixel body keypoints in, pixel-space hand keypoints out, in ONE kernel:
+        ChestDifference + /factor (steps/utils.py:180-210) -> four conv layers ->
+        x factor (traintest.py:387-388) -> optional tail mask (utils.py:309-312)."""
+        lib = self._ensure_handle()
+        x = self._check_input(body)
+        B, T = x.shape[0], x.shape[1]
+        flags = ((_lib.PRE_CHEST_DIFF if dif_encoding else 0) | (_lib.PRE_NORMALIZE if normalize else 0) |
+                 (_lib.POST_DENORMALIZE if denormalize else 0) | (_lib.POST_MASK_TAIL if mask_tail else 0))
+        nf = None
+        if mask_tail:
+            if n_frames is None:
+                raise ValueError("mask_tail needs n_frames")
+            nf = torch.as_tensor(n_frames).to(device=x.device, dtype=torch.int64).contiguous()
+            if nf.shape != (B,):
+                raise RuntimeError(f"n_frames must have shape ({B},)")
+        y = torch.empty((B, T, 21, 2), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            st = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(lib.b2h_forward_fused(self._handle, ctypes.c_void_p(x.data_ptr()),
+                                             ctypes.c_void_p(y.data_ptr()), B, T, flags, float(factor),
+                                             ctypes.c_void_p(nf.data_ptr()) if nf is not None else None,
+                                             _lib.KERNELS[self.precision], ctypes.c_void_p(st)))
+        return y
+
+    def time_forward(self, x, y, iters, precision=None):
+        """Average ms per launch over `iters` back-to-back launches, HIP events on
+        the launch stream (b2h_time_forward)."""
+        lib = self._ensure_handle()
+        ms = ctypes.c_float()
+        with torch.cuda.device(x.device):
+            st = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(lib.b2h_time_forward(self._handle, ctypes.c_void_p(x.data_ptr()),
+                                            ctypes.c_void_p(y.data_ptr()), x.shape[0], x.shape[1],
+                                            _lib.KERNELS[precision or self.precision], int(iters),
+                                            ctypes.c_void_p(st), ctypes.byref(ms)))
+        return ms.value
+
+
+def target_transform(body, hand, dif_encoding=True, normalize=True, factor=1280.0):
+    """item["target_kp"]: (hand - body[:, 4]) / factor (steps/utils.py:194-201,180-190)."""
+    lib = _lib.load()
+    if body.device.type != "cuda":
+        raise RuntimeError("target_transform runs on the GPU only")
+    body = body.to(torch.float32).contiguous()
+    hand = hand.to(device=body.device, dtype=torch.float32).contiguous()
+    B, T = body.shape[0], body.shape[1]
+    out = torch.empty_like(hand)
+    flags = (1 if dif_encoding else 0) | (2 if normalize else 0)
+    with torch.cuda.device(body.device):
+        st = torch.cuda.current_stream(body.device).cuda_stream
+        _lib.check(lib.b2h_target_transform(ctypes.c_void_p(body.data_ptr()), ctypes.c_void_p(hand.data_ptr()),
+                                            ctypes.c_void_p(out.data_ptr()), B, T, flags, float(factor),
+                                            ctypes.c_void_p(st)))
+    return out

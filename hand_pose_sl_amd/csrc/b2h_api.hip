@@ -1,0 +1,413 @@
+// libb2h.so -- C ABI (include/b2h.h) over the gfx950 kernels.
+// Host side: argument checks mirroring the reference's errors, weight repacking
+// into the kernels' fragment layouts, launches on the caller's stream.
+#include "../../include/b2h.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "b2h_common.h"
+#include "kernel_mfma.h"
+#include "kernel_valu.h"
+
+using namespace b2h;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(B2H_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+    } while (0)
+
+uint16_t f32_to_bf16(float f) { // round-to-nearest-even
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)((u >> 16) | ((u & 0xffffu) ? 0x40u : 0u));
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+uint16_t f32_to_f16(float f) { // round-to-nearest-even, IEEE binary16
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t absu = u & 0x7fffffffu;
+    if (absu >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((absu > 0x7f800000u) ? 0x200u : 0u));
+    if (absu >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u); // rounds to >= 65520 -> inf
+    if (absu < 0x38800000u) { // below 2^-14: subnormal half, grid 2^-24
+        float a;
+        std::memcpy(&a, &absu, 4);
+        const uint32_t m = (uint32_t)std::nearbyintf(a * 16777216.0f);
+        return (uint16_t)(sign | m);
+    }
+    uint32_t r = absu + 0xfffu + ((absu >> 13) & 1u);
+    return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int upload(const void* host, size_t n) {
+        if (p && bytes != n) { (void)hipFree(p); p = nullptr; }
+        if (!p) HIP_TRY(hipMalloc(&p, n));
+        bytes = n;
+        HIP_TRY(hipMemcpy(p, host, n, hipMemcpyHostToDevice));
+        return B2H_OK;
+    }
+};
+
+} // namespace
+
+struct b2h_model {
+    int C = 0;
+    int pos_emb = 0;
+    int device = 0;
+    bool has_weights = false;
+    int cin[4], cout[4];
+    // packed device weights
+    DevBuf valu_w[4], valu_b[4];
+    DevBuf mf32_w[4], mbf16_w[4], mf16_w[4], m_bias[4];
+    ValuParams vp;
+    MfmaParams mp32, mpbf16, mpf16;
+    bool lds_attr_set[8] = {false, false, false, false, false, false, false, false};
+};
+
+namespace {
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// value of weight (layer l, out-channel o, in-channel slot i, tap k); in-channel
+// slot order of layer 1 with pos_emb: slots 0..23 = reference channels 1..24
+// (keypoints), slot 24 = reference channel 0 (t/100).
+struct HostWeights {
+    const b2h_model* m;
+    std::vector<float> w[4], b[4];
+    float at(int l, int o, int slot, int k, bool permute_pos) const {
+        if (o >= m->cout[l] || slot >= m->cin[l]) return 0.f;
+        int i = slot;
+        if (l == 0 && m->pos_emb && permute_pos) i = (slot == 24) ? 0 : slot + 1;
+        return w[l][((size_t)o * m->cin[l] + i) * kTaps + k];
+    }
+    float bias(int l, int o) const { return o < m->cout[l] ? b[l][o] : 0.f; }
+};
+
+int pack_all(b2h_model* m, const HostWeights& hw) {
+    // ---- VALU layout: w[k][i][opad], reference channel order
+    for (int l = 0; l < 4; ++l) {
+        const int opad = round_up(m->cout[l], 8), cin = m->cin[l];
+        std::vector<float> w((size_t)kTaps * cin * opad, 0.f), b(opad, 0.f);
+        for (int k = 0; k < kTaps; ++k)
+            for (int i = 0; i < cin; ++i)
+                for (int o = 0; o < m->cout[l]; ++o)
+                    w[((size_t)k * cin + i) * opad + o] = hw.at(l, o, i, k, false);
+        for (int o = 0; o < m->cout[l]; ++o) b[o] = hw.b[l][o];
+        int rc = m->valu_w[l].upload(w.data(), w.size() * 4);
+        if (rc) return rc;
+        rc = m->valu_b[l].upload(b.data(), b.size() * 4);
+        if (rc) return rc;
+        m->vp.L[l] = ValuLayer{(const float*)m->valu_w[l].p, (const float*)m->valu_b[l].p, cin,
+                               m->cout[l], opad};
+    }
+    {
+        int as = round_up(m->C, 8);
+        if (as < m->cin[0]) as = m->cin[0];
+        m->vp.act_stride = as | 1;
+        int wb = 0;
+        for (int l = 0; l < 4; ++l) wb = std::max(wb, kTaps * m->vp.L[l].cin * m->vp.L[l].opad);
+        m->vp.wbuf_floats = wb;
+        m->vp.pos_emb = m->pos_emb;
+    }
+    if (m->C > kMfmaWidth) return B2H_OK; // MFMA kernels: conv_channels <= 32
+
+    // ---- MFMA layouts
+    for (int l = 0; l < 4; ++l) {
+        const int MT = (l == 3) ? 3 : 2;
+        auto chan = [&](int mt, int row) { return l == 3 ? last_chan_of(mt, row) : hidden_chan_of(mt, row); };
+        // 16-bit: [mt][tap][lane][8]
+        std::vector<uint16_t> wb((size_t)MT * kTaps * 64 * 8), wh(wb.size());
+        for (int mt = 0; mt < MT; ++mt)
+            for (int k = 0; k < kTaps; ++k)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = hw.at(l, chan(mt, lane & 15), 8 * (lane >> 4) + j, k, true);
+                        const size_t idx = (((size_t)mt * kTaps + k) * 64 + lane) * 8 + j;
+                        wb[idx] = f32_to_bf16(v);
+                        wh[idx] = f32_to_f16(v);
+                    }
+        // fp32: [mt][tap][g][lane][4]
+        std::vector<float> wf((size_t)MT * kTaps * 2 * 64 * 4);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int k = 0; k < kTaps; ++k)
+                for (int g = 0; g < 2; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j)
+                            wf[((((size_t)mt * kTaps + k) * 2 + g) * 64 + lane) * 4 + j] =
+                                hw.at(l, chan(mt, lane & 15), 16 * g + 4 * (lane >> 4) + j, k, true);
+        // bias: [mt][q][4]
+        std::vector<float> bf((size_t)MT * 16);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int q = 0; q < 4; ++q)
+                for (int r = 0; r < 4; ++r) bf[(mt * 4 + q) * 4 + r] = hw.bias(l, chan(mt, 4 * q + r));
+        int rc;
+        if ((rc = m->mbf16_w[l].upload(wb.data(), wb.size() * 2))) return rc;
+        if ((rc = m->mf16_w[l].upload(wh.data(), wh.size() * 2))) return rc;
+        if ((rc = m->mf32_w[l].upload(wf.data(), wf.size() * 4))) return rc;
+        if ((rc = m->m_bias[l].upload(bf.data(), bf.size() * 4))) return rc;
+        m->mpbf16.w[l] = m->mbf16_w[l].p;
+        m->mpf16.w[l] = m->mf16_w[l].p;
+        m->mp32.w[l] = m->mf32_w[l].p;
+        m->mpbf16.bias[l] = m->mpf16.bias[l] = m->mp32.bias[l] = (const float*)m->m_bias[l].p;
+    }
+    m->mpbf16.pos_emb = m->mpf16.pos_emb = m->mp32.pos_emb = m->pos_emb;
+    return B2H_OK;
+}
+
+int resolve_kernel(const b2h_model* m, int kernel) {
+    if (kernel == B2H_KERNEL_AUTO) return m->C <= kMfmaWidth ? B2H_KERNEL_F32_MFMA : B2H_KERNEL_F32_VALU;
+    return kernel;
+}
+
+bool kernel_ok(const b2h_model* m, int k) {
+    switch (k) {
+        case B2H_KERNEL_F32_VALU: return m->C <= kMaxWidth;
+        case B2H_KERNEL_F32_MFMA:
+        case B2H_KERNEL_BF16_MFMA:
+        case B2H_KERNEL_F16_MFMA: return m->C <= kMfmaWidth;
+        default: return false;
+    }
+}
+
+template <typename K> int ensure_lds(b2h_model* m, int slot, K kern, size_t bytes) {
+    if (bytes > 64 * 1024 && !m->lds_attr_set[slot]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        m->lds_attr_set[slot] = true;
+    }
+    return B2H_OK;
+}
+
+int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int kernel,
+           const FusedArgs& fa, hipStream_t st) {
+    if (!m) return fail(B2H_ERR_INVALID, "model is NULL");
+    if (!m->has_weights) return fail(B2H_ERR_NO_WEIGHTS, "b2h_forward before b2h_load_weights");
+    if (B < 0 || T < 1) return fail(B2H_ERR_SHAPE, "expected B >= 0 and T >= 1");
+    if (T > (1 << 24)) return fail(B2H_ERR_SHAPE, "T too large");
+    if (m->pos_emb && T != 100)
+        return fail(B2H_ERR_SHAPE, "pos_emb model requires T == 100 (LinearPositionalEmbedding max_len, "
+                                   "HandPoseModels.py:23,78-84)");
+    if (B == 0) return B2H_OK;
+    if (!x || !y) return fail(B2H_ERR_INVALID, "x / y is NULL");
+    if ((fa.flags & kPostMask) && !fa.n_frames)
+        return fail(B2H_ERR_INVALID, "B2H_POST_MASK_TAIL needs n_frames");
+    const int k = resolve_kernel(m, kernel);
+    if (!kernel_ok(m, k))
+        return fail(B2H_ERR_UNSUPPORTED, "kernel variant does not support conv_channels=" + std::to_string(m->C));
+
+    if (k == B2H_KERNEL_F32_VALU) {
+        const int tiles = (int)((T + kValuTile - 1) / kValuTile);
+        const int64_t grid = B * tiles;
+        if (grid > 0x7fffffff) return fail(B2H_ERR_SHAPE, "B*T too large for one launch");
+        const size_t lds = ((size_t)2 * kValuRows * m->vp.act_stride + m->vp.wbuf_floats) * 4;
+        int rc = ensure_lds(m, 0, b2h_fwd_f32_valu, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(b2h_fwd_f32_valu, dim3((unsigned)grid), dim3(256), lds, st, x, y, (int)T, tiles,
+                           m->vp, fa);
+    } else {
+        const int cps = (int)((T + kChunk - 1) / kChunk);
+        const int64_t nchunks = B * cps;
+        const int64_t grid = (nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (grid > 0x7fffffff) return fail(B2H_ERR_SHAPE, "B*T too large for one launch");
+        const dim3 g((unsigned)grid), blk(64 * kWavesPerBlock);
+        if (k == B2H_KERNEL_F32_MFMA) {
+            const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_F32>::kRowBytes;
+            int rc = ensure_lds(m, 1, b2h_fwd_mfma<PREC_F32>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(b2h_fwd_mfma<PREC_F32>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mp32, fa);
+        } else if (k == B2H_KERNEL_BF16_MFMA) {
+            const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_BF16>::kRowBytes;
+            int rc = ensure_lds(m, 2, b2h_fwd_mfma<PREC_BF16>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(b2h_fwd_mfma<PREC_BF16>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mpbf16, fa);
+        } else {
+            const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_F16>::kRowBytes;
+            int rc = ensure_lds(m, 3, b2h_fwd_mfma<PREC_F16>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(b2h_fwd_mfma<PREC_F16>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mpf16, fa);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return B2H_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int b2h_version(void) { return B2H_VERSION; }
+
+const char* b2h_last_error(void) { return g_err.c_str(); }
+
+int b2h_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int b2h_create(int conv_channels, const char* activation, int pos_emb, b2h_model** out) {
+    if (!out) return fail(B2H_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    // HandPoseModels.py:34-37: only "ReLU" is accepted, anything else raises ValueError
+    if (!activation || std::strcmp(activation, "ReLU") != 0)
+        return fail(B2H_ERR_INVALID, "activation must be \"ReLU\" (HandPoseModels.py:34-37)");
+    if (conv_channels < 1 || conv_channels > kMaxWidth)
+        return fail(B2H_ERR_INVALID, "conv_channels must be in [1, 64]");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return fail(B2H_ERR_NO_DEVICE, "no HIP device visible (libb2h has no CPU path)");
+    b2h_model* m = new b2h_model();
+    HIP_TRY(hipGetDevice(&m->device));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, m->device));
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        delete m;
+        return fail(B2H_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", libb2h is built for gfx950 only");
+    }
+    m->C = conv_channels;
+    m->pos_emb = pos_emb ? 1 : 0;
+    const int C = conv_channels;
+    const int cin[4] = {kInCh + m->pos_emb, C, C, C}, cout[4] = {C, C, C, kOutCh};
+    for (int l = 0; l < 4; ++l) { m->cin[l] = cin[l]; m->cout[l] = cout[l]; }
+    *out = m;
+    return B2H_OK;
+}
+
+int b2h_destroy(b2h_model* m) {
+    delete m;
+    return B2H_OK;
+}
+
+int b2h_load_weights(b2h_model* m, const float* w1, const float* b1, const float* w2, const float* b2,
+                     const float* w3, const float* b3, const float* w4, const float* b4, int on_device) {
+    if (!m) return fail(B2H_ERR_INVALID, "model is NULL");
+    const float* ws[4] = {w1, w2, w3, w4};
+    const float* bs[4] = {b1, b2, b3, b4};
+    HostWeights hw;
+    hw.m = m;
+    for (int l = 0; l < 4; ++l) {
+        if (!ws[l] || !bs[l]) return fail(B2H_ERR_INVALID, "weight pointer is NULL");
+        hw.w[l].resize((size_t)m->cout[l] * m->cin[l] * kTaps);
+        hw.b[l].resize(m->cout[l]);
+        if (on_device) {
+            HIP_TRY(hipMemcpy(hw.w[l].data(), ws[l], hw.w[l].size() * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(hw.b[l].data(), bs[l], hw.b[l].size() * 4, hipMemcpyDeviceToHost));
+        } else {
+            std::memcpy(hw.w[l].data(), ws[l], hw.w[l].size() * 4);
+            std::memcpy(hw.b[l].data(), bs[l], hw.b[l].size() * 4);
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize()); // no launch may still read the old packed buffers
+    int rc = pack_all(m, hw);
+    if (rc) return rc;
+    m->has_weights = true;
+    return B2H_OK;
+}
+
+int b2h_forward(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int kernel, void* stream) {
+    FusedArgs fa{0, 1.0f, nullptr};
+    return launch(m, x, y, B, T, kernel, fa, (hipStream_t)stream);
+}
+
+int b2h_forward_fused(b2h_model* m, const float* body, float* y, int64_t B, int64_t T, int flags, float factor,
+                      const int64_t* n_frames, int kernel, void* stream) {
+    if (flags & ~(kPreChest | kPreNorm | kPostDenorm | kPostMask)) return fail(B2H_ERR_INVALID, "unknown flag bits");
+    if ((flags & (kPreNorm | kPostDenorm)) && !(factor > 0.f)) return fail(B2H_ERR_INVALID, "factor must be > 0");
+    FusedArgs fa{flags, factor, n_frames};
+    return launch(m, body, y, B, T, kernel, fa, (hipStream_t)stream);
+}
+
+int b2h_target_transform(const float* body, const float* hand, float* hand_out, int64_t B, int64_t T, int flags,
+                         float factor, void* stream) {
+    if (B < 0 || T < 0) return fail(B2H_ERR_SHAPE, "negative shape");
+    if (B * T == 0) return B2H_OK;
+    if (!body || !hand || !hand_out) return fail(B2H_ERR_INVALID, "NULL pointer");
+    if ((flags & 2) && !(factor > 0.f)) return fail(B2H_ERR_INVALID, "factor must be > 0");
+    const int64_t n = B * T * 21;
+    const int64_t blocks = std::min<int64_t>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(b2h_target_transform_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, body,
+                       hand, hand_out, B * T, flags, factor);
+    HIP_TRY(hipGetLastError());
+    return B2H_OK;
+}
+
+int b2h_model_info(const b2h_model* m, int* conv_channels, int* pos_emb, int* has_weights) {
+    if (!m) return fail(B2H_ERR_INVALID, "model is NULL");
+    if (conv_channels) *conv_channels = m->C;
+    if (pos_emb) *pos_emb = m->pos_emb;
+    if (has_weights) *has_weights = m->has_weights ? 1 : 0;
+    return B2H_OK;
+}
+
+int b2h_kernel_supported(const b2h_model* m, int kernel) {
+    if (!m) return 0;
+    return kernel_ok(m, resolve_kernel(m, kernel)) ? 1 : 0;
+}
+
+const char* b2h_kernel_name(const b2h_model* m, int kernel) {
+    if (!m) return "";
+    switch (resolve_kernel(m, kernel)) {
+        case B2H_KERNEL_F32_VALU: return "b2h_fwd_f32_valu";
+        case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma<0>";
+        case B2H_KERNEL_BF16_MFMA: return "b2h_fwd_mfma<1>";
+        case B2H_KERNEL_F16_MFMA: return "b2h_fwd_mfma<2>";
+        default: return "";
+    }
+}
+
+int b2h_time_forward(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int kernel, int iters,
+                     void* stream, float* avg_ms) {
+    if (iters < 1 || !avg_ms) return fail(B2H_ERR_INVALID, "iters < 1 or avg_ms NULL");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    FusedArgs fa{0, 1.0f, nullptr};
+    int rc = B2H_OK;
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < iters && rc == B2H_OK; ++i) rc = launch(m, x, y, B, T, kernel, fa, st);
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    *avg_ms = ms / iters;
+    return B2H_OK;
+}
+
+int b2h_stream_sync(void* stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return B2H_OK;
+}
+
+} // extern "C"

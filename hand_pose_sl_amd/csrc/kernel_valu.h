@@ -1,0 +1,138 @@
+// fp32 vector-ALU kernel: the generic-width path (any conv_channels <= 64) and
+// the device-side cross-check for the MFMA kernels.
+//
+// One 256-thread workgroup computes 64 output frames of one sequence through
+// all four layers (HandPoseModels.py:55-58).  It loads the 80 input frames it
+// depends on (+-8 halo) straight from the native (B,T,24) layout -- the
+// reference's permute/view (:43-46) is a stride change only -- keeps both
+// activation buffers and the current layer's weights in LDS, and writes
+// (B,T,42) == (B,T,21,2) contiguous.  Activations outside [0,T) are forced to
+// zero after EVERY layer, which is what per-layer `padding=2` means.
+#pragma once
+#include "b2h_common.h"
+
+namespace b2h {
+
+constexpr int kValuTile = 64;
+constexpr int kValuRows = kValuTile + 2 * kHalo; // 80
+
+__global__ __launch_bounds__(256) void b2h_fwd_f32_valu(const float* __restrict__ x,
+                                                        float* __restrict__ y, int T,
+                                                        int tiles_per_seq, ValuParams p,
+                                                        FusedArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) float smem_valu[];
+    const int AS = p.act_stride;
+    float* act0 = smem_valu;
+    float* act1 = smem_valu + kValuRows * AS;
+    float* wbuf = smem_valu + 2 * kValuRows * AS;
+
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x / tiles_per_seq;
+    const int tile = blockIdx.x % tiles_per_seq;
+    const int t0 = tile * kValuTile;
+    const int tbase = t0 - kHalo;
+    const float* xb = x + b * (int64_t)T * kInCh;
+    const int c0 = p.pos_emb ? 1 : 0; // keypoints start at channel 1 with pos_emb (:78-84)
+
+    // ---- input rows [tbase, tbase+80), zero outside the sequence
+    for (int i = tid; i < kValuRows * (kInCh / 4); i += 256) {
+        const int r = i / (kInCh / 4), c4 = i % (kInCh / 4);
+        const int t = tbase + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T) {
+            v = *reinterpret_cast<const float4*>(xb + (int64_t)t * kInCh + c4 * 4);
+            if (fa.flags & kPreChest) { // body -= body[:,1]  (steps/utils.py:203-210)
+                const float2 ch = *reinterpret_cast<const float2*>(xb + (int64_t)t * kInCh + 2);
+                v.x -= ch.x; v.y -= ch.y; v.z -= ch.x; v.w -= ch.y;
+            }
+            if (fa.flags & kPreNorm) { // body / factor     (steps/utils.py:180-190)
+                v.x = v.x / fa.factor; v.y = v.y / fa.factor;
+                v.z = v.z / fa.factor; v.w = v.w / fa.factor;
+            }
+        }
+        float* dst = act0 + r * AS + c0 + c4 * 4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    if (p.pos_emb) // channel 0 = t/100 (HandPoseModels.py:71-75); zero outside the sequence
+        for (int r = tid; r < kValuRows; r += 256) {
+            const int t = tbase + r;
+            act0[r * AS] = (t >= 0 && t < T) ? (float)t / 100.0f : 0.f;
+        }
+
+    float* in = act0;
+    float* out = act1;
+    int64_t nvalid = T;
+    if ((fa.flags & kPostMask) && fa.n_frames) nvalid = fa.n_frames[b];
+
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        const ValuLayer L = p.L[l];
+        __syncthreads(); // previous layer done with wbuf / `in` complete
+        for (int i = tid * 4; i < kTaps * L.cin * L.opad; i += 256 * 4)
+            *reinterpret_cast<float4*>(wbuf + i) = *reinterpret_cast<const float4*>(L.w + i);
+        __syncthreads();
+
+        const int ng = L.opad / 8;
+        const int rlo = 2 * (l + 1), nrows = kValuRows - 4 * (l + 1);
+        for (int item = tid; item < nrows * ng; item += 256) {
+            const int r = rlo + item / ng, g = item % ng;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = L.b[g * 8 + j];
+            for (int k = 0; k < kTaps; ++k) {
+                const float* arow = in + (r + k - kPad) * AS;
+                const float* wk = wbuf + (size_t)k * L.cin * L.opad + g * 8;
+                for (int i = 0; i < L.cin; ++i) {
+                    const float a = arow[i];
+                    const float4 w0 = *reinterpret_cast<const float4*>(wk + i * L.opad);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wk + i * L.opad + 4);
+                    acc[0] = fmaf(a, w0.x, acc[0]); acc[1] = fmaf(a, w0.y, acc[1]);
+                    acc[2] = fmaf(a, w0.z, acc[2]); acc[3] = fmaf(a, w0.w, acc[3]);
+                    acc[4] = fmaf(a, w1.x, acc[4]); acc[5] = fmaf(a, w1.y, acc[5]);
+                    acc[6] = fmaf(a, w1.z, acc[6]); acc[7] = fmaf(a, w1.w, acc[7]);
+                }
+            }
+            const int t = tbase + r;
+            const bool inside = (t >= 0 && t < T);
+            if (l < 3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    out[r * AS + g * 8 + j] = inside ? fmaxf(acc[j], 0.f) : 0.f;
+            } else if (inside) {
+                float* yr = y + (b * (int64_t)T + t) * kOutCh + g * 8;
+                const bool dead = (int64_t)t >= nvalid;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (g * 8 + j < kOutCh) {
+                        float v = acc[j];
+                        if (fa.flags & kPostDenorm) v *= fa.factor; // traintest.py:387-388
+                        yr[j] = dead ? 0.f : v;                     // utils.py:309-312
+                    }
+            }
+        }
+        float* tmp = in; in = out; out = tmp;
+    }
+}
+
+// hand_out = (hand - body[:,4]) / factor   (steps/utils.py:194-201,180-190)
+__global__ __launch_bounds__(256) void b2h_target_transform_kernel(const float* __restrict__ body,
+                                                                   const float* __restrict__ hand,
+                                                                   float* __restrict__ out,
+                                                                   int64_t frames, int flags,
+                                                                   float factor) {
+    // one thread per (frame, joint): float2
+    const int64_t n = frames * 21;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / 21;
+        float2 v = *reinterpret_cast<const float2*>(hand + i * 2);
+        if (flags & 1) {
+            const float2 w = *reinterpret_cast<const float2*>(body + f * kInCh + 4 * 2);
+            v.x -= w.x; v.y -= w.y;
+        }
+        if (flags & 2) { v.x = v.x / factor; v.y = v.y / factor; }
+        *reinterpret_cast<float2*>(out + i * 2) = v;
+    }
+}
+
+} // namespace b2h

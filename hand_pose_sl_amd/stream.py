@@ -1,0 +1,97 @@
+"""Sequence-sharded streams over the GPUs of one node (one process per GPU).
+
+The reference is single-device; this is the MI355X-native
+scale-out of its batched caller (infer_utterance_h5.py:97-115 ->
+steps/traintest.py:353-391): utterances are independent, so the stream is
+partitioned by SEQUENCE (frames inside one sequence are coupled by the 17-frame
+receptive field) and every rank runs the fused kernel on its own shard with no
+data-path collective.  The only exchange is the optional hand-back of the
+(B_local, T, 21, 2) keypoints to rank 0, done as direct peer->root transfers
+(`torch.distributed` P2P = RCCL send/recv on ROCm): on a fully connected xGMI
+node each peer then uses its own link into rank 0 instead of a ring.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_seq, rank, world):
+    """Contiguous block partition: rank r owns [lo, hi).  Sizes differ by at most 1
+    and concatenating the shards in rank order restores the stream order."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, rem = divmod(int(n_seq), world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(n_seq, world):
+    return [shard_bounds(n_seq, r, world)[1] - shard_bounds(n_seq, r, world)[0] for r in range(world)]
+
+
+def gather_to_root(y_local, n_seq, group=None, root=0):
+    """Hand every rank's keypoints (B_local, T, 21, 2) back to `root`.
+
+    Returns the (n_seq, T, 21, 2) tensor on root (stream order), None elsewhere.
+    Shards may be unequal or empty.  Root posts one receive per peer straight
+    into its slice of the result, peers post one send: 7 concurrent xGMI links
+    into rank 0 on an 8-GPU node, no ring, no padding."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        return y_local
+    sizes = shard_sizes(n_seq, world)
+    if y_local.shape[0] != sizes[rank]:
+        raise RuntimeError(f"rank {rank}: shard has {y_local.shape[0]} sequences, expected {sizes[rank]}")
+    y_local = y_local.contiguous()
+    ops = []
+    out = None
+    if rank == root:
+        out = torch.empty((n_seq,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
+        lo, hi = shard_bounds(n_seq, rank, world)
+        out[lo:hi].copy_(y_local)
+        for r in range(world):
+            if r == root or sizes[r] == 0:
+                continue
+            lo, hi = shard_bounds(n_seq, r, world)
+            peer = dist.get_global_rank(group, r) if group is not None else r
+            ops.append(dist.P2POp(dist.irecv, out[lo:hi], peer, group))
+    elif sizes[rank] > 0:
+        peer = dist.get_global_rank(group, root) if group is not None else root
+        ops.append(dist.P2POp(dist.isend, y_local, peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
+
+
+class ShardedStream:
+    """Run a model over this rank's shard of a stream of sequences.
+
+    `model` is any callable (B,T,12,2)->(B,T,21,2) on this rank's device -- in the
+    product a `hand_pose_sl_amd.ConvModel`.  `max_batch` bounds one launch."""
+
+    def __init__(self, model, group=None, max_batch=65536):
+        self.model = model
+        self.group = group
+        self.max_batch = int(max_batch)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def local_slice(self, n_seq):
+        return shard_bounds(n_seq, self.rank, self.world)
+
+    @torch.no_grad()
+    def run_local(self, x_local):
+        if x_local.shape[0] <= self.max_batch:
+            return self.model(x_local)
+        outs = [self.model(x_local[i:i + self.max_batch]) for i in range(0, x_local.shape[0], self.max_batch)]
+        return torch.cat(outs, dim=0)
+
+    @torch.no_grad()
+    def run(self, x_local, n_seq, gather=True, root=0):
+        """x_local = this rank's sequences [lo,hi) of the stream.  Returns the full
+        result on root when gather=True (None on other ranks), else the local shard."""
+        y = self.run_local(x_local)
+        if not gather:
+            return y
+        return gather_to_root(y, n_seq, self.group, root)

@@ -1,0 +1,131 @@
+/*
+ * b2h.h -- C ABI of libb2h.so, the MI355X (gfx950) body->hand keypoint path.
+ *
+ * The reference (benoriol/hand_pose_sl) has no FFI: its boundary for this path
+ * is the Python duck type of `ConvModel` (body2hand/src/models/HandPoseModels.py
+ * :17-64).  Each entry point below names the reference interface it replaces;
+ * the Python mirror that binds them with ctypes is hand_pose_sl_amd/conv_model.py
+ * and INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*, NULL = the null stream);
+ *   - every function returns B2H_OK (0) or a negative b2h_status; the message of
+ *     the last failure on the calling thread is b2h_last_error();
+ *   - "device pointer" = memory of the current HIP device (hipMalloc or a
+ *     PyTorch-ROCm tensor's data_ptr()); the library never frees caller memory;
+ *   - launches are asynchronous on `stream`; nothing here synchronises the
+ *     device except b2h_load_weights (a one-off staging copy) and b2h_stream_sync.
+ */
+#ifndef B2H_H_
+#define B2H_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B2H_VERSION 100 /* 0.1.0 */
+
+typedef enum b2h_status {
+    B2H_OK = 0,
+    B2H_ERR_INVALID = -1,     /* bad argument (the Python mirror raises ValueError)   */
+    B2H_ERR_SHAPE = -2,       /* shape the model cannot take (RuntimeError)           */
+    B2H_ERR_NO_WEIGHTS = -3,  /* forward before b2h_load_weights                      */
+    B2H_ERR_HIP = -4,         /* a HIP runtime call failed                            */
+    B2H_ERR_NO_DEVICE = -5,   /* no gfx950 device visible                             */
+    B2H_ERR_UNSUPPORTED = -6  /* kernel variant cannot run this configuration         */
+} b2h_status;
+
+/* Which hand-written kernel computes the four-layer stack. */
+typedef enum b2h_kernel {
+    B2H_KERNEL_AUTO = 0,      /* F32_MFMA when it supports the width, else F32_VALU   */
+    B2H_KERNEL_F32_VALU = 1,  /* fp32 FMA on the vector ALU; any conv_channels <= 64   */
+    B2H_KERNEL_F32_MFMA = 2,  /* exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32)      */
+    B2H_KERNEL_BF16_MFMA = 3, /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
+    B2H_KERNEL_F16_MFMA = 4   /* fp16 operands, fp32 accumulate (v_mfma_f32_16x16x32_f16)  */
+} b2h_kernel;
+
+/* Pre/post-processing fused around the stack (b2h_forward_fused). */
+enum {
+    B2H_PRE_CHEST_DIFF = 1,   /* body -= body[:, 1]  ChestDifference, steps/utils.py:203-210 */
+    B2H_PRE_NORMALIZE = 2,    /* body /= factor      NormalizeFixedFactor, steps/utils.py:180-190 */
+    B2H_POST_DENORMALIZE = 4, /* pred *= factor      steps/traintest.py:270-271,387-388 */
+    B2H_POST_MASK_TAIL = 8    /* pred[i, n_frames[i]:] = 0   mask_output, steps/utils.py:309-312 */
+};
+
+typedef struct b2h_model b2h_model; /* opaque; owns the packed device weights */
+
+/* Library / device ------------------------------------------------------- */
+
+int b2h_version(void);
+const char* b2h_last_error(void);
+/* Number of visible HIP devices whose arch is gfx950 (0 when none). */
+int b2h_device_count(void);
+
+/* Model lifetime ---------------------------------------------------------
+ * Replaces ConvModel.__init__(conv_channels, activation, pos_emb)
+ * (HandPoseModels.py:18-37).  `activation` must be "ReLU" (B2H_ERR_INVALID
+ * otherwise, mirroring the ValueError at :34-37).  1 <= conv_channels <= 64.
+ * The model is bound to the HIP device current at creation. */
+int b2h_create(int conv_channels, const char* activation, int pos_emb, b2h_model** out);
+int b2h_destroy(b2h_model* m);
+
+/* Replaces model.load_state_dict(...) (infer_utterance.py:109,
+ * infer_utterance_h5.py:113, steps/traintest.py:62).  Tensors are fp32,
+ * contiguous, in the reference's state_dict layout:
+ *   w1 (C, 24|25, 5)  b1 (C)   w2, w3 (C, C, 5)  b2, b3 (C)   w4 (42, C, 5)  b4 (42)
+ * `on_device` != 0: the eight pointers are device pointers, else host pointers.
+ * Repacks into the kernels' fragment layouts (fp32 / bf16 / fp16) and uploads;
+ * synchronous.  May be called again to replace the weights. */
+int b2h_load_weights(b2h_model* m, const float* w1, const float* b1, const float* w2,
+                     const float* b2, const float* w3, const float* b3, const float* w4,
+                     const float* b4, int on_device);
+
+/* Replaces ConvModel.forward(inp) (HandPoseModels.py:40-64), inference only.
+ *   x : device, fp32, (B, T, 12, 2) contiguous  -- read only
+ *   y : device, fp32, (B, T, 21, 2) contiguous  -- written (value-identical to
+ *       the reference's non-contiguous view, :60-62)
+ * T >= 1; pos_emb models require T == 100 (B2H_ERR_SHAPE, as torch.cat raises
+ * in the reference, :78-84).  B == 0 is a no-op.  x and y must not overlap. */
+int b2h_forward(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int kernel,
+                void* stream);
+
+/* Forward with the reference's item transforms and de-normalisation fused in
+ * (run.py:85-90,102 order):
+ *   body : device fp32 (B, T, 12, 2) raw pixel keypoints
+ *   y    : device fp32 (B, T, 21, 2)
+ *   flags: OR of B2H_PRE_* / B2H_POST_*;  factor: 1280 in the reference
+ *   n_frames: device int64 (B) valid lengths, or NULL (required by MASK_TAIL) */
+int b2h_forward_fused(b2h_model* m, const float* body, float* y, int64_t B, int64_t T,
+                      int flags, float factor, const int64_t* n_frames, int kernel,
+                      void* stream);
+
+/* Target transform of the training item (right hand relative to the wrist):
+ *   hand_out = (hand - body[:, 4]) / factor     WristDifference + Normalize,
+ * steps/utils.py:194-201,180-190.  flags: bit0 wrist diff, bit1 normalize.
+ *   body (B,T,12,2), hand / hand_out (B,T,21,2), all device fp32. */
+int b2h_target_transform(const float* body, const float* hand, float* hand_out, int64_t B,
+                         int64_t T, int flags, float factor, void* stream);
+
+/* Introspection / measurement -------------------------------------------- */
+
+/* conv_channels, pos_emb and whether weights are loaded. */
+int b2h_model_info(const b2h_model* m, int* conv_channels, int* pos_emb, int* has_weights);
+/* 1 if `kernel` can run this model (width, pos_emb), else 0. */
+int b2h_kernel_supported(const b2h_model* m, int kernel);
+/* Name of the __global__ function `kernel` resolves to for this model (for
+ * matching rocprofv3 kernel-trace rows); static storage. */
+const char* b2h_kernel_name(const b2h_model* m, int kernel);
+/* Time `iters` back-to-back launches of b2h_forward on `stream` with HIP events
+ * recorded on that stream; returns the average milliseconds per launch. */
+int b2h_time_forward(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int kernel,
+                     int iters, void* stream, float* avg_ms);
+int b2h_stream_sync(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* B2H_H_ */

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Generate golden input/weight/output vectors from the *reference* model.
+
+Runs ONLY in the build container (needs /root/reference).  It imports the
+reference's `ConvModel` (body2hand/src/models/HandPoseModels.py:17-64) and the
+item transforms (body2hand/src/steps/utils.py:180-277,309-312) by file path,
+with an in-memory stub for the absent `fairseq` package (none of its names is
+used by the classes exercised here), runs them on seeded
+random inputs and stores inputs, weights and outputs as small .npz files.
+
+Nothing of the reference (source or bytecode) is copied: the .npz files hold
+data only.  The committed fixtures are what pins the oracle (oracle/) and,
+through it, the HIP path.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference/body2hand/src"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub_fairseq():
+    names = {
+        "fairseq": [],
+        "fairseq.utils": [],
+        "fairseq.models": [],
+        "fairseq.models.fairseq_encoder": ["EncoderOut"],
+        "fairseq.modules": ["FairseqDropout", "LayerDropModuleList", "LayerNorm",
+                            "PositionalEmbedding", "SinusoidalPositionalEmbedding",
+                            "TransformerEncoderLayer"],
+    }
+    for mod, attrs in names.items():
+        m = types.ModuleType(mod)
+        for a in attrs:
+            setattr(m, a, type(a, (), {}))
+        sys.modules[mod] = m
+    sys.modules["fairseq"].utils = sys.modules["fairseq.utils"]
+
+
+def _load(path, name):
+    sys.dont_write_bytecode = True
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _inputs(kind, shape, gen):
+    if kind == "randn":
+        return torch.randn(shape, generator=gen)
+    if kind == "u01":
+        return torch.rand(shape, generator=gen)
+    if kind == "u55":
+        return torch.rand(shape, generator=gen) - 0.5
+    raise ValueError(kind)
+
+
+def conv_case(hpm, name, B, T, C, pos_emb, kind, seed, keep=None):
+    """One ConvModel forward.  keep=(n_head_seq) stores only some sequences of
+    the output for big batches (the input is regenerated from the seed by the
+    test, weights are always stored in full)."""
+    torch.manual_seed(seed)
+    model = hpm.ConvModel(C, "ReLU", pos_emb)
+    model.eval()
+    gen = torch.Generator().manual_seed(seed + 1)
+    x = _inputs(kind, (B, T, 12, 2), gen)
+    with torch.no_grad():
+        y = model(x).contiguous()
+    sd = {k.replace(".", "_"): v.numpy() for k, v in model.state_dict().items()}
+    rec = dict(sd)
+    rec["meta"] = np.array([B, T, C, int(pos_emb), seed], dtype=np.int64)
+    rec["kind"] = np.array(kind)
+    if keep is None:
+        rec["x"] = x.numpy()
+        rec["y"] = y.numpy()
+    else:
+        idx = np.array(keep, dtype=np.int64)
+        rec["x"] = x.numpy()                      # inputs are small (96 B/frame)
+        rec["y_idx"] = idx
+        rec["y"] = y.numpy()[idx]
+        # whole-output checksums in float64 so a test can check every element
+        rec["y_sum"] = np.array(y.double().sum().item())
+        rec["y_abs_sum"] = np.array(y.double().abs().sum().item())
+        rec["y_row_sum"] = y.double().sum(dim=(1, 2, 3)).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: x{tuple(x.shape)} -> y{tuple(y.shape)}  |y|max={y.abs().max():.4f}")
+
+
+def transform_case(utils, hpm, name, T, n_frames, seed):
+    """Pre/post-processing around the model exactly as run.py:83-107 orders it:
+    WristDifference, ChestDifference, NormalizeFixedFactor(1280),
+    BuildRightHandItem -> ConvModel -> x1280 (traintest.py:387-388) ->
+    mask_output (steps/utils.py:309-312)."""
+    gen = torch.Generator().manual_seed(seed)
+    B = len(n_frames)
+    body = torch.rand((B, T, 12, 2), generator=gen) * torch.tensor([1280.0, 720.0])
+    rhand = torch.rand((B, T, 21, 2), generator=gen) * torch.tensor([1280.0, 720.0])
+    lhand = torch.rand((B, T, 21, 2), generator=gen) * torch.tensor([1280.0, 720.0])
+    tf = [utils.WristDifference(), utils.ChestDifference(),
+          utils.NormalizeFixedFactor(1280), utils.BuildRightHandItem()]
+    items = []
+    for b in range(B):
+        item = {"body_kp": body[b].clone(), "right_hand_kp": rhand[b].clone(),
+                "left_hand_kp": lhand[b].clone(),
+                "body_conf": torch.ones(T, 12), "right_hand_conf": torch.ones(T, 21)}
+        for t in tf:
+            item = t(item)
+        items.append(item)
+    inp = torch.stack([it["input_kp"] for it in items])
+    tgt = torch.stack([it["target_kp"] for it in items])
+    torch.manual_seed(seed)
+    model = hpm.ConvModel(30, "ReLU", False).eval()
+    with torch.no_grad():
+        pred = model(inp).contiguous()
+        pred_px = pred * 1280
+        masked = utils.mask_output(pred_px.clone(), n_frames)
+    rec = {k.replace(".", "_"): v.numpy() for k, v in model.state_dict().items()}
+    rec.update(body=body.numpy(), right_hand=rhand.numpy(), n_frames=np.array(n_frames),
+               input_kp=inp.numpy(), target_kp=tgt.numpy(), pred=pred.numpy(),
+               pred_px=pred_px.numpy(), pred_px_masked=masked.numpy(),
+               meta=np.array([B, T, 30, 0, seed], dtype=np.int64))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: body{tuple(body.shape)} -> pred_px{tuple(masked.shape)}")
+
+
+def main():
+    _stub_fairseq()
+    hpm = _load(os.path.join(REF, "models", "HandPoseModels.py"), "ref_HandPoseModels")
+    utils = _load(os.path.join(REF, "steps", "utils.py"), "ref_steps_utils")
+
+    # BASELINE.json config 1: single sequence / single frame, CPU plumbing
+    conv_case(hpm, "cfg1_b1_t200", 1, 200, 30, False, "randn", 0)
+    conv_case(hpm, "cfg1_b1_t1", 1, 1, 30, False, "randn", 1)
+    # edge lengths around the 5-tap kernel and the 17-frame receptive field
+    for T in (2, 3, 5, 8, 16, 17, 18, 33, 199, 201, 257, 600):
+        conv_case(hpm, f"edge_b3_t{T}", 3, T, 30, False, "u55", 100 + T)
+    # positional-embedding branch (requires T == 100)
+    conv_case(hpm, "posemb_b2_t100", 2, 100, 30, True, "u01", 7)
+    # other widths
+    for C in (8, 16, 32, 64):
+        conv_case(hpm, f"width_c{C}_b2_t50", 2, 50, C, False, "randn", 200 + C)
+    # BASELINE.json config 2: batch=64, three input distributions
+    for kind in ("randn", "u01", "u55"):
+        conv_case(hpm, f"cfg2_b64_t200_{kind}", 64, 200, 30, False, kind, 0,
+                  keep=[0, 1, 31, 62, 63])
+    # pre/post-processing
+    transform_case(utils, hpm, "transforms_b6_t40", 40, [40, 1, 17, 39, 25, 8], 11)
+
+
+if __name__ == "__main__":
+    main()
