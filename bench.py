@@ -41,8 +41,8 @@ DTYPE = {"bf16": "bf16", "f16": "f16", "f32_mfma": "f32", "f32_valu": "f32", "fp
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--seqs", type=int, default=65536, help="sequences per GPU per step")
     ap.add_argument("--frames", type=int, default=200, help="T, frames per sequence (--max-frames default, run.py:28)")
     ap.add_argument("--precision", default="bf16", choices=sorted(MFMA_PEAK_TFLOPS))

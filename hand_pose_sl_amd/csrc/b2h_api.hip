@@ -7,12 +7,14 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "b2h_common.h"
 #include "kernel_mfma.h"
+#include "kernel_mfma16.h"
 #include "kernel_valu.h"
 
 using namespace b2h;
@@ -82,6 +84,8 @@ struct b2h_model {
     // packed device weights
     DevBuf valu_w[4], valu_b[4];
     DevBuf mf32_w[4], mbf16_w[4], mf16_w[4], m_bias[4];
+    DevBuf mbf16_all, mf16_all; // persistent 16-bit kernel: [W L0..L3 | bias L0..L3], kPacked16 bytes
+    int num_cus = 256;
     ValuParams vp;
     MfmaParams mp32, mpbf16, mpf16;
     bool lds_attr_set[8] = {false, false, false, false, false, false, false, false};
@@ -174,6 +178,20 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
         m->mpbf16.bias[l] = m->mpf16.bias[l] = m->mp32.bias[l] = (const float*)m->m_bias[l].p;
     }
     m->mpbf16.pos_emb = m->mpf16.pos_emb = m->mp32.pos_emb = m->pos_emb;
+    {   // contiguous image the persistent kernel copies into LDS once per workgroup
+        std::vector<unsigned char> ab(kPacked16, 0), ah(kPacked16, 0);
+        for (int l = 0; l < 4; ++l) {
+            const int MT = (l == 3) ? 3 : 2;
+            const size_t wbytes = (size_t)MT * kTaps * kWFrag16, bbytes = (size_t)MT * 64;
+            HIP_TRY(hipMemcpy(ab.data() + kWLayerOff16[l], m->mbf16_w[l].p, wbytes, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(ah.data() + kWLayerOff16[l], m->mf16_w[l].p, wbytes, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(ab.data() + kBiasOff16[l], m->m_bias[l].p, bbytes, hipMemcpyDeviceToHost));
+            std::memcpy(ah.data() + kBiasOff16[l], ab.data() + kBiasOff16[l], bbytes);
+        }
+        int rc;
+        if ((rc = m->mbf16_all.upload(ab.data(), ab.size()))) return rc;
+        if ((rc = m->mf16_all.upload(ah.data(), ah.size()))) return rc;
+    }
     return B2H_OK;
 }
 
@@ -238,16 +256,40 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             int rc = ensure_lds(m, 1, b2h_fwd_mfma<PREC_F32>, lds);
             if (rc) return rc;
             hipLaunchKernelGGL(b2h_fwd_mfma<PREC_F32>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mp32, fa);
-        } else if (k == B2H_KERNEL_BF16_MFMA) {
-            const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_BF16>::kRowBytes;
-            int rc = ensure_lds(m, 2, b2h_fwd_mfma<PREC_BF16>, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL(b2h_fwd_mfma<PREC_BF16>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mpbf16, fa);
+        } else if (std::getenv("B2H_MFMA16_V1")) { // development A/B: first-generation 16-bit kernel
+            if (k == B2H_KERNEL_BF16_MFMA) {
+                const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_BF16>::kRowBytes;
+                int rc = ensure_lds(m, 2, b2h_fwd_mfma<PREC_BF16>, lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL(b2h_fwd_mfma<PREC_BF16>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mpbf16, fa);
+            } else {
+                const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_F16>::kRowBytes;
+                int rc = ensure_lds(m, 3, b2h_fwd_mfma<PREC_F16>, lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL(b2h_fwd_mfma<PREC_F16>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mpf16, fa);
+            }
         } else {
-            const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_F16>::kRowBytes;
-            int rc = ensure_lds(m, 3, b2h_fwd_mfma<PREC_F16>, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL(b2h_fwd_mfma<PREC_F16>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mpf16, fa);
+            // persistent kernel: one 512-thread workgroup per CU
+            const int TT = (T <= kChunkWhole16) ? kChunkWhole16 : kChunkSplit16;
+            const int cps16 = (int)((T + TT - 1) / TT);
+            const int64_t nch = B * cps16;
+            const unsigned grid16 = (unsigned)std::min<int64_t>(m->num_cus, nch);
+            const bool fused = fa.flags != 0;
+            const bool bf = (k == B2H_KERNEL_BF16_MFMA);
+            const void* wp = bf ? m->mbf16_all.p : m->mf16_all.p;
+            int rc = B2H_OK;
+#define B2H_LAUNCH16(PR, FU, SLOT)                                                                      \
+    do {                                                                                                \
+        rc = ensure_lds(m, SLOT, b2h_fwd_mfma16<PR, FU>, kLds16);                                       \
+        if (rc) return rc;                                                                              \
+        hipLaunchKernelGGL((b2h_fwd_mfma16<PR, FU>), dim3(grid16), dim3(64 * kWaves16), kLds16, st, x, y, \
+                           (int)T, cps16, TT, nch, wp, m->pos_emb, fa);                                 \
+    } while (0)
+            if (bf && !fused) B2H_LAUNCH16(PREC_BF16, false, 4);
+            else if (bf) B2H_LAUNCH16(PREC_BF16, true, 5);
+            else if (!fused) B2H_LAUNCH16(PREC_F16, false, 6);
+            else B2H_LAUNCH16(PREC_F16, true, 7);
+#undef B2H_LAUNCH16
         }
     }
     HIP_TRY(hipGetLastError());
@@ -292,6 +334,7 @@ int b2h_create(int conv_channels, const char* activation, int pos_emb, b2h_model
         delete m;
         return fail(B2H_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", libb2h is built for gfx950 only");
     }
+    m->num_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     m->C = conv_channels;
     m->pos_emb = pos_emb ? 1 : 0;
     const int C = conv_channels;
@@ -377,8 +420,8 @@ const char* b2h_kernel_name(const b2h_model* m, int kernel) {
     switch (resolve_kernel(m, kernel)) {
         case B2H_KERNEL_F32_VALU: return "b2h_fwd_f32_valu";
         case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma<0>";
-        case B2H_KERNEL_BF16_MFMA: return "b2h_fwd_mfma<1>";
-        case B2H_KERNEL_F16_MFMA: return "b2h_fwd_mfma<2>";
+        case B2H_KERNEL_BF16_MFMA: return std::getenv("B2H_MFMA16_V1") ? "b2h_fwd_mfma<1>" : "b2h_fwd_mfma16<1, false>";
+        case B2H_KERNEL_F16_MFMA: return std::getenv("B2H_MFMA16_V1") ? "b2h_fwd_mfma<2>" : "b2h_fwd_mfma16<2, false>";
         default: return "";
     }
 }
