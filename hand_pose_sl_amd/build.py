@@ -40,6 +40,8 @@ def build(force=False, verbose=False):
     cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function",
            "-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    if os.environ.get("B2H_ABLATE"):  # development: timing-only ablation builds (kernel_mfma16.h)
+        cmd.insert(1, "-DB2H_ABLATE=" + os.environ["B2H_ABLATE"])
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

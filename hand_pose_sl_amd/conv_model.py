@@ -87,8 +87,8 @@ class ConvModel(nn.Module):
                 _lib.load().b2h_destroy(self._handle)
             except Exception:
                 pass
-            self._handle = None
-            self._packed_key = None
+            self.__dict__["_handle"] = None
+            self.__dict__["_packed_key"] = None
 
     def __del__(self):
         self._free()

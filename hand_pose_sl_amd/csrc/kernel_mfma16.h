@@ -9,8 +9,9 @@
 //   per chunk, per wave:
 //     commit   : the chunk's (T,24) fp32 rows, already waiting in registers, are
 //                cast and written to this wave's LDS image [time][32 ch] (64-B rows)
-//     prefetch : the NEXT chunk's rows are requested from HBM into the same
-//                registers (up to 21 x 16 B per lane) and fly during the math
+//     prefetch : the NEXT chunk's rows are requested from HBM into registers (20 x 16 B
+//                per lane), fly under layers 1-2, and are cast to 16 bit in registers
+//                before the register-hungry head
 //     layers   : per 16-frame tile 5 ds_read_b128 (one per tap) feed 10 (15 for the
 //                head) v_mfma_f32_16x16x32; D = W[chan][(tap,ch)] x Act[(tap,ch)][time]
 //                starts from the bias fragment; ReLU (integer max), zero-padding
@@ -24,6 +25,13 @@
 #pragma once
 #include "b2h_common.h"
 #include "kernel_mfma.h"
+
+// Development only: -DB2H_ABLATE=<bits> builds a timing-only variant with parts of the
+// kernel removed (1 no MFMA, 2 no global stores, 4 no global loads, 8 no fragment
+// reads, 16 no write-back).  Results are wrong by construction; never shipped.
+#ifndef B2H_ABLATE
+#define B2H_ABLATE 0
+#endif
 
 namespace b2h {
 
@@ -74,57 +82,90 @@ __device__ __forceinline__ Geom16 geom16(int64_t chunk, int cps, int TT, int T) 
     return g;
 }
 
-struct InRegs { float4 v[kInRegs]; };
+struct InRegs { float4 v[kInRegs]; };   // next chunk's rows as loaded (fp32)
+struct InRegs16 { uint2 p[kInRegs]; };  // the same, cast to 4 x 16-bit
 
-__device__ __forceinline__ void issue_loads16(InRegs& R, const float* __restrict__ x, const Geom16& g,
-                                              int T, int lane) {
-    const float4* src = reinterpret_cast<const float4*>(x + (g.seq * (int64_t)T + g.in_lo) * kInCh);
+// Buffer descriptor over [base, base + bytes): loads past the end return 0 and stores
+// past the end are dropped by the hardware range check, so one VGPR byte offset
+// (plus SGPR/immediate offsets) addresses everything and no lane predicate is needed.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, bytes, 0x00020000);
+}
+
+// Request a chunk's input rows: 20 x 16 B per lane, lane-contiguous (coalesced 1 KiB
+// per instruction).  bytes == 0 (nothing left to prefetch) issues no memory traffic.
+__device__ __forceinline__ void issue_loads16(InRegs& R, const float* base, int bytes, int lane) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
 #pragma unroll
     for (int j = 0; j < kInRegs; ++j) {
-        const int i = lane + 64 * j;
-        R.v[j] = (i < g.nf4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (B2H_ABLATE & 4) { R.v[j] = make_float4(0.25f, 0.5f, -0.25f, 0.125f); continue; }
+        const i32x4 r = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0));
+        R.v[j] = __builtin_bit_cast(float4, r);
     }
 }
 
-// registers -> LDS image of the layer-1 input (P(t,0) = t - s + 8).
+__device__ __forceinline__ void pin_loads16(InRegs& R) {
+    static_assert(kInRegs == 20, "operand groups below assume 20 float4");
+#define B2H_PIN4(TXT, a, b, c, d)                                                                        \
+    asm volatile(TXT : "+v"(R.v[a].x), "+v"(R.v[a].y), "+v"(R.v[a].z), "+v"(R.v[a].w), "+v"(R.v[b].x),  \
+                 "+v"(R.v[b].y), "+v"(R.v[b].z), "+v"(R.v[b].w), "+v"(R.v[c].x), "+v"(R.v[c].y),        \
+                 "+v"(R.v[c].z), "+v"(R.v[c].w), "+v"(R.v[d].x), "+v"(R.v[d].y), "+v"(R.v[d].z),        \
+                 "+v"(R.v[d].w)::"memory")
+    B2H_PIN4("s_waitcnt vmcnt(0)", 0, 1, 2, 3);
+    B2H_PIN4("", 4, 5, 6, 7);
+    B2H_PIN4("", 8, 9, 10, 11);
+    B2H_PIN4("", 12, 13, 14, 15);
+    B2H_PIN4("", 16, 17, 18, 19);
+#undef B2H_PIN4
+}
+
+__device__ __forceinline__ void pin_regs16(InRegs16& Q) {
+#pragma unroll
+    for (int j = 0; j < kInRegs; j += 4)
+        asm volatile("" : "+v"(Q.p[j].x), "+v"(Q.p[j].y), "+v"(Q.p[j + 1].x), "+v"(Q.p[j + 1].y),
+                     "+v"(Q.p[j + 2].x), "+v"(Q.p[j + 2].y), "+v"(Q.p[j + 3].x), "+v"(Q.p[j + 3].y)::"memory");
+}
+
 // Three load iterations (192 float4) cover exactly 32 rows, so a lane needs only
-// three (row, column) pairs; every other address is one of those plus a multiple
-// of 32 rows = 2048 B, which also leaves the swizzle term unchanged.
-template <int PREC, bool FUSED>
-__device__ __forceinline__ void commit16(const InRegs& R, char* lds, const float* __restrict__ x,
-                                         const Geom16& g, int T, int lane, int pos_emb,
-                                         const FusedArgs& fa) {
-    const int P0 = g.in_lo + 8 - g.s; // physical row of the first loaded frame: 0, or 8 at s == 0
-    char* base = lds + P0 * 64;      // (P0 is a multiple of 8: swizzle term unchanged)
-    int rr[3], off[3];
+// three (row, column) pairs: iteration j = 3G + jj touches row 32G + rr[jj].
+__device__ __forceinline__ void lane_rows16(int lane, int (&rr)[3], int (&c4)[3]) {
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {
         const int u = lane + 64 * jj;
         rr[jj] = u / 6;
-        const int c4 = u - rr[jj] * 6;
-        off[jj] = lds_off<64>(rr[jj], c4 >> 1) + (c4 & 1) * 8;
+        c4[jj] = u - rr[jj] * 6;
     }
+}
+
+// fp32 registers -> packed 16-bit registers (runs mid-chunk, when the loads have
+// long landed).
+template <int PREC>
+__device__ __forceinline__ void convert16(const InRegs& R, InRegs16& Q) {
+#pragma unroll
+    for (int j = 0; j < kInRegs; ++j)
+        Q.p[j] = uint2{pack2<PREC>(R.v[j].x, R.v[j].y), pack2<PREC>(R.v[j].z, R.v[j].w)};
+}
+
+// packed registers -> LDS image of the layer-1 input (P(t,0) = t - s + 8).  Every
+// address is one of three per-lane offsets plus a multiple of 32 rows = 2048 B,
+// which leaves the swizzle term unchanged.
+template <int PREC>
+__device__ __forceinline__ void commit16(const InRegs16& Q, char* lds, const Geom16& g, int T,
+                                         int lane, int pos_emb) {
+    const int P0 = g.in_lo + 8 - g.s; // physical row of the first loaded frame: 0, or 8 at s == 0
+    char* base = lds + P0 * 64;      // (P0 is a multiple of 8: swizzle term unchanged)
+    int rr[3], c4[3], off[3];
+    lane_rows16(lane, rr, c4);
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) off[jj] = lds_off<64>(rr[jj], c4[jj] >> 1) + (c4[jj] & 1) * 8;
 #pragma unroll
     for (int j = 0; j < kInRegs; ++j) {
         constexpr int kGroupBytes = 32 * 64;
-        const int G = j / 3, jj = j % 3;
-        const int i = lane + 64 * j;
-        if (i < g.nf4) {
-            float4 v = R.v[j];
-            if constexpr (FUSED) {
-                const int t = g.in_lo + 32 * G + rr[jj];
-                if (fa.flags & kPreChest) { // body -= body[:,1] (steps/utils.py:203-210)
-                    const float2 ch = *reinterpret_cast<const float2*>(x + (g.seq * (int64_t)T + t) * kInCh + 2);
-                    v.x -= ch.x; v.y -= ch.y; v.z -= ch.x; v.w -= ch.y;
-                }
-                if (fa.flags & kPreNorm) { // body / factor (steps/utils.py:180-190)
-                    v.x = v.x / fa.factor; v.y = v.y / fa.factor;
-                    v.z = v.z / fa.factor; v.w = v.w / fa.factor;
-                }
-            }
-            uint2 o = {pack2<PREC>(v.x, v.y), pack2<PREC>(v.z, v.w)};
-            *reinterpret_cast<uint2*>(base + G * kGroupBytes + off[jj]) = o;
-        }
+        if (lane + 64 * j < g.nf4)
+            *reinterpret_cast<uint2*>(base + (j / 3) * kGroupBytes + off[j % 3]) = Q.p[j];
     }
     // channels 24..31: zero (pos_emb: slot 24 = t/100, HandPoseModels.py:71-75)
     const int nrows = g.nf4 / 6;
@@ -148,10 +189,9 @@ __device__ __forceinline__ void commit16(const InRegs& R, char* lds, const float
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int PREC, int L, bool FUSED>
+template <int PREC, int L>
 __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom16& g, int T,
-                                         int lane, float* __restrict__ yseq, const FusedArgs& fa,
-                                         int64_t nvalid) {
+                                         int lane, float* __restrict__ yseq) {
     using P = Prec<PREC>;
     using vec8 = typename P::vec8;
     constexpr int MT = (L == 3) ? 3 : 2;
@@ -180,18 +220,25 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
     for (int s = 0; s < kTaps; ++s) rd[s] = lds_off<64>(lo + tcol + s - kPad + pin, q);
     int wr = lds_off<64>(lo + tcol + pout, q);
 
-#pragma unroll 1
-    for (int m = 0; m < ntiles; ++m) {
-        vec8 Bf[kTaps];
-#pragma unroll
-        for (int s = 0; s < kTaps; ++s) Bf[s] = *reinterpret_cast<const vec8*>(lds + rd[s] + m * 1024);
+    // head only: output rows [0, e) of this sequence as a buffer, lane byte offset of tile 0
+    __amdgpu_buffer_rsrc_t yrs;
+    int yoff = 0;
+    if constexpr (L == 3) {
+        yrs = make_rsrc(yseq, g.e * (kOutCh * 4));
+        yoff = (lo + tcol) * (kOutCh * 4) + 16 * q;
+    }
+    // One tile: 10/15 MFMAs on fragments already in registers, then the epilogue.
+    auto tile = [&](const vec8 (&Bf)[kTaps], int m) {
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = bias[mt];
 #pragma unroll
         for (int s = 0; s < kTaps; ++s)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = P::mfma(A[mt][s], Bf[s], acc[mt]);
+            for (int mt = 0; mt < MT; ++mt) {
+                if (B2H_ABLATE & 1) { acc[mt][0] += (float)Bf[s][0]; continue; }
+                acc[mt] = P::mfma(A[mt][s], Bf[s], acc[mt]);
+            }
 
         const int tau = lo + 16 * m;
         if constexpr (L < 3) {
@@ -207,29 +254,46 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
             }
             uint4 o = {pack2<PREC>(v[0], v[1]), pack2<PREC>(v[2], v[3]), pack2<PREC>(v[4], v[5]),
                        pack2<PREC>(v[6], v[7])};
-            *reinterpret_cast<uint4*>(lds + wr + m * 1024) = o;
+            if (!(B2H_ABLATE & 16) || T < 0) *reinterpret_cast<uint4*>(lds + wr + m * 1024) = o;
+            else asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
         } else {
-            const int t = tau + tcol;
-            if (t < g.e) {
-                float* yr = yseq + (int64_t)t * kOutCh + 4 * q;
-                bool dead = false;
-                if constexpr (FUSED) dead = (int64_t)t >= nvalid;
+            if ((B2H_ABLATE & 2) && T > 0) { asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0])); }
+            else {
+                // lane (tcol,q) owns channels 16mt + 4q .. +3 of frame tau + tcol: 16 B at
+                // row offset 168 t + 64 mt + 16 q; frames >= e fall outside the descriptor
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) {
-                    f32x4 v = acc[mt];
-                    if constexpr (FUSED) {
-                        if (fa.flags & kPostDenorm) v = v * fa.factor; // traintest.py:387-388
-                        if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};      // utils.py:309-312
-                    }
-                    if (mt < 2 || q < 2) {
-                        *reinterpret_cast<float2*>(yr + 16 * mt) = float2{v[0], v[1]};
-                        *reinterpret_cast<float2*>(yr + 16 * mt + 2) = float2{v[2], v[3]};
-                    } else if (q == 2) {
-                        *reinterpret_cast<float2*>(yr + 16 * mt) = float2{v[0], v[1]};
-                    }
+                    const f32x4 v = acc[mt];
+                    const int so = m * (16 * kOutCh * 4) + mt * 64;
+                    if (mt < 2 || q < 2)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff, so, 0);
+                    else if (q == 2) // channels 40, 41
+                        // (elements passed BY VALUE: __builtin_bit_cast on an ext-vector element
+                        // lvalue reads element 0 in this clang)
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])},
+                                                              yrs, yoff, so, 0);
                 }
             }
         }
+    };
+    auto fetch = [&](vec8 (&Bf)[kTaps], int m) {
+#pragma unroll
+        for (int s = 0; s < kTaps; ++s) {
+            if ((B2H_ABLATE & 8) && T > 0) { Bf[s] = A[0][s]; continue; }
+            Bf[s] = *reinterpret_cast<const vec8*>(lds + rd[s] + m * 1024);
+        }
+    };
+    // Software pipeline, ping-pong fragment registers: tile m+1's fragments are read
+    // while tile m multiplies.  Legal because tile m writes rows [tau-2, tau+14) of the
+    // next image and tile m+1 reads rows [tau+14, tau+34) of this one (same buffer).
+    vec8 B0[kTaps], B1[kTaps];
+    fetch(B0, 0);
+#pragma unroll 1
+    for (int m = 0; m < ntiles; m += 2) {
+        if (m + 1 < ntiles) fetch(B1, m + 1);
+        tile(B0, m);
+        if (m + 2 < ntiles) fetch(B0, m + 2);
+        if (m + 1 < ntiles) tile(B1, m + 1);
     }
     if constexpr (L < 3) {
         if (hi == T) { // sequence end: next layer reads frames T, T+1 as zeros
@@ -243,10 +307,10 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
     }
 }
 
-template <int PREC, bool FUSED>
+template <int PREC>
 __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     const float* __restrict__ x, float* __restrict__ y, int T, int cps, int TT, int64_t nchunks,
-    const void* __restrict__ wpacked, int pos_emb, FusedArgs fa) {
+    const void* __restrict__ wpacked, int pos_emb) {
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     // weights + biases of all four layers: one copy per workgroup
     for (int i = threadIdx.x; i < kPacked16 / 16; i += 64 * kWaves16)
@@ -260,26 +324,34 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     int64_t chunk = blockIdx.x + (int64_t)gridDim.x * wave; // consecutive chunks -> different CUs
     if (chunk >= nchunks) return;
 
+    auto src_of = [&](const Geom16& gg) { return x + (gg.seq * (int64_t)T + gg.in_lo) * kInCh; };
     InRegs R;
+    InRegs16 Q;
     Geom16 g = geom16(chunk, cps, TT, T);
-    issue_loads16(R, x, g, T, lane);
+    issue_loads16(R, src_of(g), g.nf4 * 16, lane);
+    convert16<PREC>(R, Q);
     while (true) {
-        commit16<PREC, FUSED>(R, lds, x, g, T, lane, pos_emb, fa);
+        commit16<PREC>(Q, lds, g, T, lane, pos_emb);
         const int64_t next = chunk + stride;
         const bool more = next < nchunks;
-        Geom16 gn = g;
-        if (more) {
-            gn = geom16(next, cps, TT, T);
-            issue_loads16(R, x, gn, T, lane); // flies under the four layers below
-        }
+        // prefetch the next chunk; unconditional (an empty buffer when nothing is left)
+        // so that the register lifetimes below do not depend on control flow
+        const Geom16 gn = more ? geom16(next, cps, TT, T) : g;
+        issue_loads16(R, src_of(gn), more ? gn.nf4 * 16 : 0, lane); // flies under layers 1-2
         float* yseq = y + g.seq * (int64_t)T * kOutCh;
-        int64_t nvalid = T;
-        if constexpr (FUSED)
-            if ((fa.flags & kPostMask) && fa.n_frames) nvalid = fa.n_frames[g.seq];
-        layer16p<PREC, 0, FUSED>(lds, smem16, g, T, lane, yseq, fa, nvalid);
-        layer16p<PREC, 1, FUSED>(lds, smem16, g, T, lane, yseq, fa, nvalid);
-        layer16p<PREC, 2, FUSED>(lds, smem16, g, T, lane, yseq, fa, nvalid);
-        layer16p<PREC, 3, FUSED>(lds, smem16, g, T, lane, yseq, fa, nvalid);
+        layer16p<PREC, 0>(lds, smem16, g, T, lane, yseq);
+        layer16p<PREC, 1>(lds, smem16, g, T, lane, yseq);
+        // The prefetch has had two layers to land.  Wait for it HERE -- the only vector-memory
+        // operations still in flight are those loads and the previous chunk's (older) stores,
+        // so vmcnt(0) does not wait for anything younger -- and cast it to 16 bit now (80 -> 40
+        // registers before the wide head).  The asm operands pin both the wait and the cast to
+        // this point: left alone, hipcc sinks the cast below the head and its wait then also
+        // drains this chunk's 52 output stores.
+        pin_loads16(R);
+        convert16<PREC>(R, Q);
+        pin_regs16(Q);
+        layer16p<PREC, 2>(lds, smem16, g, T, lane, yseq);
+        layer16p<PREC, 3>(lds, smem16, g, T, lane, yseq);
         if (!more) break;
         chunk = next;
         g = gn;
