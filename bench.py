@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=200, help="T, frames per sequence (--max-frames default, run.py:28)")
     ap.add_argument("--precision", default="bf16", choices=sorted(MFMA_PEAK_TFLOPS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--gather", action="store_true",
                     help="also time handing a config-4 stream (2000 seq) back to rank 0 (reported aside)")
     return ap.parse_args()
@@ -60,12 +60,26 @@ def cpu_baseline(model, seconds):
     import torch
 
     import oracle
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # The GPU box gives one GPU's job a share of 16 host cores (cpu_count reports the whole
+    # 256-thread host; running torch on all of them is 1000x slower through oversubscription).
+    # Probe a few thread counts for ~1 s each and time the sample with the best one.
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     port = oracle.TorchPort(state, pos_emb=False)
     g = torch.Generator().manual_seed(0)
     x = torch.rand((256, 200, 12, 2), generator=g) - 0.5
+    best, cores = 0.0, 1
+    for nt in sorted({1, min(8, avail), min(16, avail)}):
+        torch.set_num_threads(nt)
+        port(x)
+        k, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 1.0:
+            port(x)
+            k += 1
+        rate = k / (time.perf_counter() - t0)
+        if rate > best:
+            best, cores = rate, nt
+    torch.set_num_threads(cores)
     for _ in range(3):
         y_cpu = port(x)
     n, t0 = 0, time.perf_counter()
@@ -73,7 +87,7 @@ def cpu_baseline(model, seconds):
         y_cpu = port(x)
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 20000:
+        if el >= seconds or n >= 200000:
             break
     fps = n * 256 * 200 / el
     # the same sample through the HIP path, checked against the CPU result
@@ -83,7 +97,7 @@ def cpu_baseline(model, seconds):
     err = float((y_gpu - y_cpu.contiguous()).abs().max())
     return {"value": fps, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"(256,200,12,2) U[-0.5,0.5] x {n} passes in {el:.1f} s, torch {torch.__version__} "
-                      f"Conv1d x4 fp32 (oracle/torch_port.py)",
+                      f"Conv1d x4 fp32 (oracle/torch_port.py), best of 1/8/16 threads (host share of one GPU)",
             "gflops": fps * FLOP_PER_FRAME / 1e9, "gpu_max_abs_err_on_sample": err}
 
 

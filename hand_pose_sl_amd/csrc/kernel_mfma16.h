@@ -28,7 +28,7 @@
 
 // Development only: -DB2H_ABLATE=<bits> builds a timing-only variant with parts of the
 // kernel removed (1 no MFMA, 2 no global stores, 4 no global loads, 8 no fragment
-// reads, 16 no write-back).  Results are wrong by construction; never shipped.
+// reads, 16 no write-back, 32 lane-linear output stores).  Results are wrong by construction; never shipped.
 #ifndef B2H_ABLATE
 #define B2H_ABLATE 0
 #endif
@@ -161,11 +161,13 @@ __device__ __forceinline__ void commit16(const InRegs16& Q, char* lds, const Geo
     lane_rows16(lane, rr, c4);
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) off[jj] = lds_off<64>(rr[jj], c4[jj] >> 1) + (c4[jj] & 1) * 8;
+    // No lane predicate: lanes past the chunk's last float4 hold the zeros the buffer load's
+    // range check returned, and their rows (<= row 221 of 224) are either the zero padding
+    // after the sequence end or rows no tile of this chunk depends on.
 #pragma unroll
     for (int j = 0; j < kInRegs; ++j) {
         constexpr int kGroupBytes = 32 * 64;
-        if (lane + 64 * j < g.nf4)
-            *reinterpret_cast<uint2*>(base + (j / 3) * kGroupBytes + off[j % 3]) = Q.p[j];
+        *reinterpret_cast<uint2*>(base + (j / 3) * kGroupBytes + off[j % 3]) = Q.p[j];
     }
     // channels 24..31: zero (pos_emb: slot 24 = t/100, HandPoseModels.py:71-75)
     const int nrows = g.nf4 / 6;
@@ -227,9 +229,8 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
         yrs = make_rsrc(yseq, g.e * (kOutCh * 4));
         yoff = (lo + tcol) * (kOutCh * 4) + 16 * q;
     }
-    // One tile: 10/15 MFMAs on fragments already in registers, then the epilogue.
-    auto tile = [&](const vec8 (&Bf)[kTaps], int m) {
-        f32x4 acc[MT];
+    // M: the 10 (15) MFMAs of one tile on fragments already in registers.
+    auto mma = [&](f32x4 (&acc)[MT], const vec8 (&Bf)[kTaps]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = bias[mt];
 #pragma unroll
@@ -239,7 +240,9 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
                 if (B2H_ABLATE & 1) { acc[mt][0] += (float)Bf[s][0]; continue; }
                 acc[mt] = P::mfma(A[mt][s], Bf[s], acc[mt]);
             }
-
+    };
+    // E: epilogue of tile m.
+    auto epi = [&](const f32x4 (&acc)[MT], int m) {
         const int tau = lo + 16 * m;
         if constexpr (L < 3) {
             float v[8];
@@ -265,6 +268,10 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
                 for (int mt = 0; mt < 3; ++mt) {
                     const f32x4 v = acc[mt];
                     const int so = m * (16 * kOutCh * 4) + mt * 64;
+                    if (B2H_ABLATE & 32) { // timing probe: same bytes, lane-linear (perfectly coalesced, wrong layout)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, lane * 16, (m * 3 + mt) * 1024, 0);
+                        continue;
+                    }
                     if (mt < 2 || q < 2)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff, so, 0);
                     else if (q == 2) // channels 40, 41
@@ -276,6 +283,9 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
             }
         }
     };
+    // F: tile m's five fragments.  Unconditional: past the last tile it reads rows that
+    // nobody uses (LDS reads beyond the allocation return 0), which keeps the loop free
+    // of branches between the MFMAs and the epilogue they overlap with.
     auto fetch = [&](vec8 (&Bf)[kTaps], int m) {
 #pragma unroll
         for (int s = 0; s < kTaps; ++s) {
@@ -283,18 +293,26 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
             Bf[s] = *reinterpret_cast<const vec8*>(lds + rd[s] + m * 1024);
         }
     };
-    // Software pipeline, ping-pong fragment registers: tile m+1's fragments are read
-    // while tile m multiplies.  Legal because tile m writes rows [tau-2, tau+14) of the
-    // next image and tile m+1 reads rows [tau+14, tau+34) of this one (same buffer).
+    // Software pipeline over tiles, two deep: fragments are read two tiles ahead (ping-pong
+    // B0/B1) and a tile's epilogue runs one tile late (ping-pong accA/accB), next to the
+    // following tile's MFMAs, so the matrix pipe does not wait for VALU/LDS work.
+    // Legal in the in-place image: tile m writes rows [tau-2, tau+14) of the next image,
+    // every fragment read issued before that write belongs to tiles <= m+2, and tiles > m
+    // read rows >= tau+14.
     vec8 B0[kTaps], B1[kTaps];
+    f32x4 accA[MT], accB[MT];
     fetch(B0, 0);
+    fetch(B1, 1);
+    mma(accA, B0); // tile 0
+    fetch(B0, 2);
+    int m = 1;
 #pragma unroll 1
-    for (int m = 0; m < ntiles; m += 2) {
-        if (m + 1 < ntiles) fetch(B1, m + 1);
-        tile(B0, m);
-        if (m + 2 < ntiles) fetch(B0, m + 2);
-        if (m + 1 < ntiles) tile(B1, m + 1);
+    for (; m + 1 < ntiles; m += 2) {
+        mma(accB, B1); epi(accA, m - 1); fetch(B1, m + 2);
+        mma(accA, B0); epi(accB, m);     fetch(B0, m + 3);
     }
+    if (m < ntiles) { mma(accB, B1); epi(accA, m - 1); epi(accB, m); }
+    else epi(accA, m - 1);
     if constexpr (L < 3) {
         if (hi == T) { // sequence end: next layer reads frames T, T+1 as zeros
             const int t = T + (lane >> 2);
@@ -321,7 +339,9 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     const int lane = threadIdx.x & 63;
     char* lds = smem16 + kPacked16 + wave * kWaveLds16;
     const int64_t stride = (int64_t)gridDim.x * kWaves16;
-    int64_t chunk = blockIdx.x + (int64_t)gridDim.x * wave; // consecutive chunks -> different CUs
+    // consecutive chunks -> different CUs, so small batches spread over the chip (taking 8
+    // consecutive chunks per workgroup instead measured the same on a full stream)
+    int64_t chunk = blockIdx.x + (int64_t)gridDim.x * wave;
     if (chunk >= nchunks) return;
 
     auto src_of = [&](const Geom16& gg) { return x + (gg.seq * (int64_t)T + gg.in_lo) * kInCh; };
