@@ -190,9 +190,17 @@ def main():
                            "bytes_per_launch": alg_bytes,
                            "mfma_tflops": tfl, "mfma_peak_tflops": MFMA_PEAK_TFLOPS[args.precision],
                            "mfma_frac": tfl / MFMA_PEAK_TFLOPS[args.precision]}
-        traffic = os.environ.get("B2H_PMC_TRAFFIC_BYTES")  # filled from profiles/ when re-run after a --pmc pass
-        if traffic:
-            out["roofline"]["traffic"] = float(traffic)
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/profile.sh):
+        # counters cannot be read inside this run, so the committed figure for this exact
+        # workload and kernel is reported; null for any other configuration.
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_final", "traffic.json")))
+            if (tj["seqs_per_gpu"], tj["frames_per_seq"]) == (S, T) and tj["kernel"] in model.kernel_name() \
+                    and tj["precision"] == args.precision:
+                out["roofline"]["traffic"] = tj["traffic_bytes"]
+                out["roofline"]["traffic_source"] = "profiles/r1_final/traffic.json"
+        except (OSError, KeyError, ValueError):
+            pass
 
     if args.gather and world >= 1:
         from hand_pose_sl_amd.stream import ShardedStream, shard_bounds
