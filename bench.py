@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=sorted(MFMA_PEAK_TFLOPS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on a 1-GPU box)")
     ap.add_argument("--gather", action="store_true",
                     help="also time handing a config-4 stream (2000 seq) back to rank 0 (reported aside)")
     return ap.parse_args()
@@ -117,10 +119,15 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU path in the product)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev          # one rank per GPU on a real node; wraps only in 1-GPU rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     S, T = args.seqs, args.frames
     torch.manual_seed(0)

@@ -256,10 +256,7 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             int rc = ensure_lds(m, 1, b2h_fwd_mfma<PREC_F32>, lds);
             if (rc) return rc;
             hipLaunchKernelGGL(b2h_fwd_mfma<PREC_F32>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mp32, fa);
-        } else if (fa.flags != 0 || std::getenv("B2H_MFMA16_V1")) {
-            // Fused pre/post-processing runs on the per-wave (non-persistent) 16-bit kernel:
-            // the persistent kernel below is transform-free (open items).
-            // B2H_MFMA16_V1 forces this kernel for A/B timing during development.
+        } else if (std::getenv("B2H_MFMA16_V1")) { // development A/B: per-wave (non-persistent) 16-bit kernel
             if (k == B2H_KERNEL_BF16_MFMA) {
                 const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_BF16>::kRowBytes;
                 int rc = ensure_lds(m, 2, b2h_fwd_mfma<PREC_BF16>, lds);
@@ -277,17 +274,22 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             const int cps16 = (int)((T + TT - 1) / TT);
             const int64_t nch = B * cps16;
             const unsigned grid16 = (unsigned)std::min<int64_t>(m->num_cus, nch);
-            if (k == B2H_KERNEL_BF16_MFMA) {
-                int rc = ensure_lds(m, 4, b2h_fwd_mfma16<PREC_BF16>, kLds16);
-                if (rc) return rc;
-                hipLaunchKernelGGL(b2h_fwd_mfma16<PREC_BF16>, dim3(grid16), dim3(64 * kWaves16), kLds16, st, x, y,
-                                   (int)T, cps16, TT, nch, m->mbf16_all.p, m->pos_emb);
-            } else {
-                int rc = ensure_lds(m, 6, b2h_fwd_mfma16<PREC_F16>, kLds16);
-                if (rc) return rc;
-                hipLaunchKernelGGL(b2h_fwd_mfma16<PREC_F16>, dim3(grid16), dim3(64 * kWaves16), kLds16, st, x, y,
-                                   (int)T, cps16, TT, nch, m->mf16_all.p, m->pos_emb);
-            }
+            const bool fused = fa.flags != 0;
+            const bool bf = (k == B2H_KERNEL_BF16_MFMA);
+            const void* wp = bf ? m->mbf16_all.p : m->mf16_all.p;
+            int rc = B2H_OK;
+#define B2H_LAUNCH16(PR, FU, SLOT)                                                                        \
+    do {                                                                                                  \
+        rc = ensure_lds(m, SLOT, b2h_fwd_mfma16<PR, FU>, kLds16);                                         \
+        if (rc) return rc;                                                                                \
+        hipLaunchKernelGGL((b2h_fwd_mfma16<PR, FU>), dim3(grid16), dim3(64 * kWaves16), kLds16, st, x, y, \
+                           (int)T, cps16, TT, nch, wp, m->pos_emb, fa);                                   \
+    } while (0)
+            if (bf && !fused) B2H_LAUNCH16(PREC_BF16, false, 4);
+            else if (bf) B2H_LAUNCH16(PREC_BF16, true, 5);
+            else if (!fused) B2H_LAUNCH16(PREC_F16, false, 6);
+            else B2H_LAUNCH16(PREC_F16, true, 7);
+#undef B2H_LAUNCH16
         }
     }
     HIP_TRY(hipGetLastError());
@@ -418,8 +420,8 @@ const char* b2h_kernel_name(const b2h_model* m, int kernel) {
     switch (resolve_kernel(m, kernel)) {
         case B2H_KERNEL_F32_VALU: return "b2h_fwd_f32_valu";
         case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma<0>";
-        case B2H_KERNEL_BF16_MFMA: return std::getenv("B2H_MFMA16_V1") ? "b2h_fwd_mfma<1>" : "b2h_fwd_mfma16<1>";
-        case B2H_KERNEL_F16_MFMA: return std::getenv("B2H_MFMA16_V1") ? "b2h_fwd_mfma<2>" : "b2h_fwd_mfma16<2>";
+        case B2H_KERNEL_BF16_MFMA: return std::getenv("B2H_MFMA16_V1") ? "b2h_fwd_mfma<1>" : "b2h_fwd_mfma16<1, false>";
+        case B2H_KERNEL_F16_MFMA: return std::getenv("B2H_MFMA16_V1") ? "b2h_fwd_mfma<2>" : "b2h_fwd_mfma16<2, false>";
         default: return "";
     }
 }

@@ -140,13 +140,40 @@ __device__ __forceinline__ void lane_rows16(int lane, int (&rr)[3], int (&c4)[3]
     }
 }
 
-// fp32 registers -> packed 16-bit registers (runs mid-chunk, when the loads have
-// long landed).
-template <int PREC>
-__device__ __forceinline__ void convert16(const InRegs& R, InRegs16& Q) {
+// Fused pre/post-processing parameters, resolved to wave-uniform scalars ONCE at kernel
+// entry (no per-lane select on a uniform flag anywhere): see FusedArgs.
+struct Fused16 {
+    bool chest;   // body -= body[:,1]             ChestDifference, steps/utils.py:203-210
+    bool norm;    // body /= factor                NormalizeFixedFactor, steps/utils.py:180-190
+    float factor;
+    float mul;    // factor if de-normalising, else 1.0f (x1.0f is exact)   traintest.py:387-388
+    bool mask;    // pred[i, n_frames[i]:] = 0     mask_output, steps/utils.py:309-312
+};
+
+// fp32 registers -> packed 16-bit registers (runs mid-chunk, when the loads have long
+// landed); the reference's item transforms are applied here when fused.
+template <int PREC, bool FUSED>
+__device__ __forceinline__ void convert16(const InRegs& R, InRegs16& Q, const float* __restrict__ xrow0,
+                                          int nf4, int lane, const Fused16& fu) {
+    int rr[3], c4[3];
+    if constexpr (FUSED) lane_rows16(lane, rr, c4);
 #pragma unroll
-    for (int j = 0; j < kInRegs; ++j)
-        Q.p[j] = uint2{pack2<PREC>(R.v[j].x, R.v[j].y), pack2<PREC>(R.v[j].z, R.v[j].w)};
+    for (int j = 0; j < kInRegs; ++j) {
+        float4 v = R.v[j];
+        if constexpr (FUSED) {
+            if (fu.chest) { // wave-uniform branch
+                float2 ch = make_float2(0.f, 0.f);
+                if (lane + 64 * j < nf4) // row of this float4, channels 2..3 = joint 1 (chest)
+                    ch = *reinterpret_cast<const float2*>(xrow0 + (32 * (j / 3) + rr[j % 3]) * kInCh + 2);
+                v.x -= ch.x; v.y -= ch.y; v.z -= ch.x; v.w -= ch.y;
+            }
+            if (fu.norm) { // wave-uniform branch; true division like the reference
+                v.x = v.x / fu.factor; v.y = v.y / fu.factor;
+                v.z = v.z / fu.factor; v.w = v.w / fu.factor;
+            }
+        }
+        Q.p[j] = uint2{pack2<PREC>(v.x, v.y), pack2<PREC>(v.z, v.w)};
+    }
 }
 
 // packed registers -> LDS image of the layer-1 input (P(t,0) = t - s + 8).  Every
@@ -191,9 +218,9 @@ __device__ __forceinline__ void commit16(const InRegs16& Q, char* lds, const Geo
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int PREC, int L>
+template <int PREC, int L, bool FUSED>
 __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom16& g, int T,
-                                         int lane, float* __restrict__ yseq) {
+                                         int lane, float* __restrict__ yseq, float mul, int nvalid) {
     using P = Prec<PREC>;
     using vec8 = typename P::vec8;
     constexpr int MT = (L == 3) ? 3 : 2;
@@ -264,9 +291,14 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
             else {
                 // lane (tcol,q) owns channels 16mt + 4q .. +3 of frame tau + tcol: 16 B at
                 // row offset 168 t + 64 mt + 16 q; frames >= e fall outside the descriptor
+                const bool dead = FUSED && (tau + tcol >= nvalid); // tail mask (per lane)
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) {
-                    const f32x4 v = acc[mt];
+                    f32x4 v = acc[mt];
+                    if constexpr (FUSED) {
+                        v = v * mul;                               // x factor, or x 1.0f (exact)
+                        if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                     const int so = m * (16 * kOutCh * 4) + mt * 64;
                     if (B2H_ABLATE & 32) { // timing probe: same bytes, lane-linear (perfectly coalesced, wrong layout)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, lane * 16, (m * 3 + mt) * 1024, 0);
@@ -325,10 +357,10 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
     }
 }
 
-template <int PREC>
+template <int PREC, bool FUSED>
 __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     const float* __restrict__ x, float* __restrict__ y, int T, int cps, int TT, int64_t nchunks,
-    const void* __restrict__ wpacked, int pos_emb) {
+    const void* __restrict__ wpacked, int pos_emb, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     // weights + biases of all four layers: one copy per workgroup
     for (int i = threadIdx.x; i < kPacked16 / 16; i += 64 * kWaves16)
@@ -345,11 +377,20 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     if (chunk >= nchunks) return;
 
     auto src_of = [&](const Geom16& gg) { return x + (gg.seq * (int64_t)T + gg.in_lo) * kInCh; };
+    Fused16 fu;
+    {
+        const int flags = FUSED ? __builtin_amdgcn_readfirstlane(fa.flags) : 0;
+        fu.chest = flags & kPreChest;
+        fu.norm = flags & kPreNorm;
+        fu.factor = fa.factor;
+        fu.mul = (flags & kPostDenorm) ? fa.factor : 1.0f;
+        fu.mask = (flags & kPostMask) && fa.n_frames;
+    }
     InRegs R;
     InRegs16 Q;
     Geom16 g = geom16(chunk, cps, TT, T);
     issue_loads16(R, src_of(g), g.nf4 * 16, lane);
-    convert16<PREC>(R, Q);
+    convert16<PREC, FUSED>(R, Q, src_of(g), g.nf4, lane, fu);
     while (true) {
         commit16<PREC>(Q, lds, g, T, lane, pos_emb);
         const int64_t next = chunk + stride;
@@ -357,10 +398,14 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
         // prefetch the next chunk; unconditional (an empty buffer when nothing is left)
         // so that the register lifetimes below do not depend on control flow
         const Geom16 gn = more ? geom16(next, cps, TT, T) : g;
-        issue_loads16(R, src_of(gn), more ? gn.nf4 * 16 : 0, lane); // flies under layers 1-2
+        const int nf4n = more ? gn.nf4 : 0;
+        issue_loads16(R, src_of(gn), nf4n * 16, lane); // flies under layers 1-2
         float* yseq = y + g.seq * (int64_t)T * kOutCh;
-        layer16p<PREC, 0>(lds, smem16, g, T, lane, yseq);
-        layer16p<PREC, 1>(lds, smem16, g, T, lane, yseq);
+        int nvalid = T;
+        if constexpr (FUSED)
+            if (fu.mask) nvalid = (int)min((int64_t)T, max((int64_t)0, fa.n_frames[g.seq]));
+        layer16p<PREC, 0, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
+        layer16p<PREC, 1, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
         // The prefetch has had two layers to land.  Wait for it HERE -- the only vector-memory
         // operations still in flight are those loads and the previous chunk's (older) stores,
         // so vmcnt(0) does not wait for anything younger -- and cast it to 16 bit now (80 -> 40
@@ -368,10 +413,10 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
         // this point: left alone, hipcc sinks the cast below the head and its wait then also
         // drains this chunk's 52 output stores.
         pin_loads16(R);
-        convert16<PREC>(R, Q);
+        convert16<PREC, FUSED>(R, Q, src_of(gn), nf4n, lane, fu);
         pin_regs16(Q);
-        layer16p<PREC, 2>(lds, smem16, g, T, lane, yseq);
-        layer16p<PREC, 3>(lds, smem16, g, T, lane, yseq);
+        layer16p<PREC, 2, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
+        layer16p<PREC, 3, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
         if (!more) break;
         chunk = next;
         g = gn;
