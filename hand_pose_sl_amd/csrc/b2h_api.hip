@@ -253,21 +253,9 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         const dim3 g((unsigned)grid), blk(64 * kWavesPerBlock);
         if (k == B2H_KERNEL_F32_MFMA) {
             const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_F32>::kRowBytes;
-            int rc = ensure_lds(m, 1, b2h_fwd_mfma<PREC_F32>, lds);
+            int rc = ensure_lds(m, 1, b2h_fwd_mfma_f32, lds);
             if (rc) return rc;
-            hipLaunchKernelGGL(b2h_fwd_mfma<PREC_F32>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mp32, fa);
-        } else if (std::getenv("B2H_MFMA16_V1")) { // development A/B: per-wave (non-persistent) 16-bit kernel
-            if (k == B2H_KERNEL_BF16_MFMA) {
-                const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_BF16>::kRowBytes;
-                int rc = ensure_lds(m, 2, b2h_fwd_mfma<PREC_BF16>, lds);
-                if (rc) return rc;
-                hipLaunchKernelGGL(b2h_fwd_mfma<PREC_BF16>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mpbf16, fa);
-            } else {
-                const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_F16>::kRowBytes;
-                int rc = ensure_lds(m, 3, b2h_fwd_mfma<PREC_F16>, lds);
-                if (rc) return rc;
-                hipLaunchKernelGGL(b2h_fwd_mfma<PREC_F16>, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mpf16, fa);
-            }
+            hipLaunchKernelGGL(b2h_fwd_mfma_f32, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mp32, fa);
         } else {
             // persistent kernel: one 512-thread workgroup per CU
             const int TT = (T <= kChunkWhole16) ? kChunkWhole16 : kChunkSplit16;
@@ -419,9 +407,9 @@ const char* b2h_kernel_name(const b2h_model* m, int kernel) {
     if (!m) return "";
     switch (resolve_kernel(m, kernel)) {
         case B2H_KERNEL_F32_VALU: return "b2h_fwd_f32_valu";
-        case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma<0>";
-        case B2H_KERNEL_BF16_MFMA: return std::getenv("B2H_MFMA16_V1") ? "b2h_fwd_mfma<1>" : "b2h_fwd_mfma16<1, false>";
-        case B2H_KERNEL_F16_MFMA: return std::getenv("B2H_MFMA16_V1") ? "b2h_fwd_mfma<2>" : "b2h_fwd_mfma16<2, false>";
+        case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma_f32";
+        case B2H_KERNEL_BF16_MFMA: return "b2h_fwd_mfma16<1, false>";
+        case B2H_KERNEL_F16_MFMA: return "b2h_fwd_mfma16<2, false>";
         default: return "";
     }
 }

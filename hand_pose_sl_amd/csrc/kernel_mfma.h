@@ -1,28 +1,25 @@
-// Fused four-layer temporal-conv stack on the gfx950 matrix cores.
+// Exact-fp32 matrix-core kernel (v_mfma_f32_16x16x4_f32) and the pieces it shares with the
+// persistent 16-bit kernel (kernel_mfma16.h): precision traits, the swizzled LDS image.
 //
-// Path: ConvModel.forward, HandPoseModels.py:40-64.  One WAVE owns one chunk of
-// one sequence (a whole sequence when T <= kChunk) and carries it through all
-// four layers with no workgroup barrier:
+// Path: ConvModel.forward, HandPoseModels.py:40-64.  One WAVE owns one chunk of one
+// sequence (a whole sequence when T <= kChunk) and carries it through all four layers with
+// no workgroup barrier:
 //
-//   x (B,T,24) fp32 --coalesced 16-B loads--> [cvt] --> LDS rows [time][32 ch]
+//   x (B,T,24) fp32 --coalesced 16-B loads--> LDS rows [time][32 ch] fp32 (128-B rows)
 //   layer l:  D[chan][time] += W_l[chan][(tap,ch)] * Act[(tap,ch)][time]
-//             A = weights (fragment-ordered, registers), B = activations: with
-//             32 padded channels per row one 16x16x32 k-step is exactly one
-//             tap, so lane (tcol,q) reads the 16 B "row time+tap-2, chunk q".
-//             The accumulator starts from the bias fragment; ReLU, the
-//             per-layer zero padding mask (t >= T -> 0) and the bf16 cast are
-//             applied in registers and written back as one 16-B chunk per lane.
+//             A = weights (fragment-ordered, registers), B = activations; the accumulator
+//             starts from the bias fragment; ReLU and the per-layer zero padding mask
+//             (t >= T -> 0) are applied in registers and written back 16 B per lane.
 //   layer 4:  42 channels as 3 M-tiles, stored straight to y (B,T,42) fp32.
 //
 // In-place LDS: layer l+1's input row for time t lives 2 rows BELOW layer l's
-// (P(t,l) = t - s + 8 - 2l), so tile m's write-back can never touch a row that
-// tiles > m still have to read; one buffer per wave instead of two.
-// Rows for t < 0 are zeroed once and never written; rows T, T+1 are re-zeroed
-// after each layer at the sequence end.
+// (P(t,l) = t - s + 8 - 2l), so tile m's write-back can never touch a row that tiles > m
+// still have to read; one buffer per wave instead of two.  Rows for t < 0 are zeroed once
+// and never written; rows T, T+1 are re-zeroed after each layer at the sequence end.
 //
-// LDS image: 16-B chunk c of physical row P is stored at chunk c ^ ((P>>1)&3)
-// (64-B rows): conflict-free for the ds_read_b128 fragment reads at every row
-// alignment and for the ds_write_b128 write-back (tools/lds_bank_check.py).
+// 16-bit LDS image (used by kernel_mfma16.h): 16-B chunk c of physical row P is stored at
+// chunk c ^ ((P>>1)&3) (64-B rows): conflict-free for the ds_read_b128 fragment reads at
+// every row alignment and for the ds_write_b128 write-back.
 #pragma once
 #include "b2h_common.h"
 
@@ -34,7 +31,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kChunk = 208;            // output frames per wave-chunk (13 tiles of 16)
+constexpr int kChunk = 112;            // output frames per wave-chunk: 18 KB of LDS per wave, so two
+                                       // 4-wave workgroups share a CU (2 waves/SIMD); T=200 -> 112 + 88
 constexpr int kRows = kChunk + 32;     // 8 halo + chunk + 8 halo + 16 tile overrun
 constexpr int kWavesPerBlock = 4;
 
@@ -75,103 +73,6 @@ struct ChunkCtx {
     FusedArgs fa;
     int64_t nvalid; // frames kept by the tail mask
 };
-
-// ---- 16-bit operand layers --------------------------------------------------
-template <int PREC, int L>
-__device__ __forceinline__ void layer16(const ChunkCtx& cx, const MfmaParams& mp) {
-    using P = Prec<PREC>;
-    using vec8 = typename P::vec8;
-    constexpr int MT = (L == 3) ? 3 : 2;
-    constexpr int h = 6 - 2 * L; // rows of halo this layer's output still needs
-    const int lo = max(cx.s - h, 0), hi = min(cx.e + h, cx.T);
-    const int ntiles = (hi - lo + 15) >> 4;
-
-    // weights + bias fragments for this layer (L2-resident, 10-15 KB)
-    vec8 A[MT][kTaps];
-    f32x4 bias[MT];
-    {
-        const uint4* wp = reinterpret_cast<const uint4*>(mp.w[L]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int s = 0; s < kTaps; ++s) {
-                uint4 raw = wp[(mt * kTaps + s) * 64 + cx.lane];
-                A[mt][s] = __builtin_bit_cast(vec8, raw);
-            }
-        const f32x4* bp = reinterpret_cast<const f32x4*>(mp.bias[L]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) bias[mt] = bp[mt * 4 + cx.q];
-    }
-
-    const int pin = 8 - 2 * L - cx.s;  // P(t, L)   = t + pin
-    const int pout = pin - 2;          // P(t, L+1) = t + pout
-
-#pragma unroll 1
-    for (int m = 0; m < ntiles; ++m) {
-        const int tau = lo + 16 * m;
-        vec8 Bf[kTaps];
-#pragma unroll
-        for (int s = 0; s < kTaps; ++s) {
-            const int Pr = tau + cx.tcol + s - kPad + pin;
-            Bf[s] = *reinterpret_cast<const vec8*>(cx.lds + lds_off<64>(Pr, cx.q));
-        }
-        f32x4 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = bias[mt];
-#pragma unroll
-        for (int s = 0; s < kTaps; ++s)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = P::mfma(A[mt][s], Bf[s], acc[mt]);
-
-        const int t = tau + cx.tcol;
-        if constexpr (L < 3) {
-            const bool inside = t < cx.T; // per-layer zero padding (HandPoseModels.py:55-57)
-            vec8 o;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = fmaxf(acc[mt][r], 0.f);
-                    v = inside ? v : 0.f;
-                    o[mt * 4 + r] = (typename P::elem)v;
-                }
-            *reinterpret_cast<vec8*>(cx.lds + lds_off<64>(t + pout, cx.q)) = o;
-        } else {
-            if (t < cx.e) { // e <= T
-                float* yr = cx.y + (int64_t)t * kOutCh + 4 * cx.q;
-                const bool dead = (int64_t)t >= cx.nvalid;
-#pragma unroll
-                for (int mt = 0; mt < 3; ++mt) {
-                    f32x4 v = acc[mt];
-                    if (cx.fa.flags & kPostDenorm) v = v * cx.fa.factor;
-                    if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (mt < 2 || cx.q < 2) {
-                        *reinterpret_cast<float2*>(yr + 16 * mt) = float2{v[0], v[1]};
-                        *reinterpret_cast<float2*>(yr + 16 * mt + 2) = float2{v[2], v[3]};
-                    } else if (cx.q == 2) {
-                        *reinterpret_cast<float2*>(yr + 16 * mt) = float2{v[0], v[1]};
-                    }
-                }
-            }
-        }
-    }
-    if constexpr (L < 3) {
-        // sequence end: the next layer reads times T, T+1 as zero padding
-        if (hi == cx.T) {
-            const int covered = lo + 16 * ntiles;
-            const int t = cx.T + (cx.lane >> 2);
-            if (cx.lane < 8 && t >= covered) {
-                vec8 z;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = (typename P::elem)0.f;
-                *reinterpret_cast<vec8*>(cx.lds + lds_off<64>(t + pout, cx.lane & 3)) = z;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
 
 // ---- exact-fp32 layers (v_mfma_f32_16x16x4_f32) -------------------------------
 template <int L>
@@ -264,34 +165,36 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
 }
 
 // ---- input staging: (T,24) fp32 rows -> LDS image of layer-1 input ------------
-template <int PREC>
-__device__ __forceinline__ void stage_input(const ChunkCtx& cx, const float* __restrict__ xs,
-                                            int pos_emb) {
-    constexpr int ROWB = Prec<PREC>::kRowBytes;
+__device__ __forceinline__ void stage_input32(const ChunkCtx& cx, const float* __restrict__ xs, int pos_emb) {
     const int in_lo = max(cx.s - kHalo, 0), in_hi = min(cx.e + kHalo, cx.T);
     const int pin = 8 - cx.s; // P(t,0) = t + pin
     const int nf4 = (in_hi - in_lo) * (kInCh / 4);
     const float4* src = reinterpret_cast<const float4*>(xs + (int64_t)in_lo * kInCh);
-    for (int i = cx.lane; i < nf4; i += 64) {
-        float4 v = src[i];
-        const int rr = i / 6, c4 = i - rr * 6;
-        const int t = in_lo + rr;
-        if (cx.fa.flags & kPreChest) {
-            const float2 ch = *reinterpret_cast<const float2*>(xs + (int64_t)t * kInCh + 2);
-            v.x -= ch.x; v.y -= ch.y; v.z -= ch.x; v.w -= ch.y;
+    // batches of 8 loads in flight per lane (serial load->use per iteration exposes the HBM
+    // latency once per float4)
+    for (int i0 = cx.lane; i0 < nf4; i0 += 64 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u;
+            v[u] = (i < nf4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (cx.fa.flags & kPreNorm) {
-            v.x = v.x / cx.fa.factor; v.y = v.y / cx.fa.factor;
-            v.z = v.z / cx.fa.factor; v.w = v.w / cx.fa.factor;
-        }
-        const int Pr = t + pin;
-        if constexpr (PREC == PREC_F32) {
-            *reinterpret_cast<float4*>(cx.lds + lds_off<128>(Pr, c4)) = v;
-        } else {
-            using vec4 = typename Prec<PREC>::vec4;
-            using elem = typename Prec<PREC>::elem;
-            vec4 o = {(elem)v.x, (elem)v.y, (elem)v.z, (elem)v.w};
-            *reinterpret_cast<vec4*>(cx.lds + lds_off<64>(Pr, c4 >> 1) + (c4 & 1) * 8) = o;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u;
+            if (i >= nf4) continue;
+            const int rr = i / 6, c4 = i - rr * 6;
+            const int t = in_lo + rr;
+            float4 w = v[u];
+            if (cx.fa.flags & kPreChest) { // body -= body[:,1]  (steps/utils.py:203-210)
+                const float2 ch = *reinterpret_cast<const float2*>(xs + (int64_t)t * kInCh + 2);
+                w.x -= ch.x; w.y -= ch.y; w.z -= ch.x; w.w -= ch.y;
+            }
+            if (cx.fa.flags & kPreNorm) { // body / factor     (steps/utils.py:180-190)
+                w.x = w.x / cx.fa.factor; w.y = w.y / cx.fa.factor;
+                w.z = w.z / cx.fa.factor; w.w = w.w / cx.fa.factor;
+            }
+            *reinterpret_cast<float4*>(cx.lds + lds_off<128>(t + pin, c4)) = w;
         }
     }
     // channel padding 24..31 (pos_emb: channel 24 = t/100, HandPoseModels.py:71-75;
@@ -300,50 +203,24 @@ __device__ __forceinline__ void stage_input(const ChunkCtx& cx, const float* __r
     for (int r = cx.lane; r < nrows; r += 64) {
         const int t = in_lo + r, Pr = t + pin;
         const float pe = pos_emb ? (float)t / 100.0f : 0.f;
-        if constexpr (PREC == PREC_F32) {
-            *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(Pr, 6)) = f32x4{pe, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(Pr, 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-            using vec8 = typename Prec<PREC>::vec8;
-            using elem = typename Prec<PREC>::elem;
-            vec8 z;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = (elem)0.f;
-            z[0] = (elem)pe;
-            *reinterpret_cast<vec8*>(cx.lds + lds_off<64>(Pr, 3)) = z;
-        }
+        *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(Pr, 6)) = f32x4{pe, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(Pr, 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // zero rows: t in [-8,0) at the sequence start (all layers' low padding) and
     // t = T, T+1 at the sequence end
-    constexpr int CPR = ROWB / 16; // chunks per row
-    if (cx.s == 0) {
-        for (int i = cx.lane; i < 8 * CPR; i += 64)
-            *reinterpret_cast<f32x4*>(cx.lds + lds_off<ROWB>(i / CPR, i % CPR)) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (in_hi == cx.T) {
-        for (int i = cx.lane; i < 2 * CPR; i += 64)
-            *reinterpret_cast<f32x4*>(cx.lds + lds_off<ROWB>(cx.T + i / CPR + pin, i % CPR)) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    if (cx.s == 0)
+        for (int i = cx.lane; i < 8 * 8; i += 64)
+            *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(i / 8, i % 8)) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (in_hi == cx.T)
+        for (int i = cx.lane; i < 2 * 8; i += 64)
+            *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(cx.T + i / 8 + pin, i % 8)) = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int PREC>
-__device__ __forceinline__ void run_chunk(ChunkCtx& cx, const float* __restrict__ xs,
-                                          const MfmaParams& mp) {
-    stage_input<PREC>(cx, xs, mp.pos_emb);
-    if constexpr (PREC == PREC_F32) {
-        layer32<0>(cx, mp); layer32<1>(cx, mp); layer32<2>(cx, mp); layer32<3>(cx, mp);
-    } else {
-        layer16<PREC, 0>(cx, mp); layer16<PREC, 1>(cx, mp);
-        layer16<PREC, 2>(cx, mp); layer16<PREC, 3>(cx, mp);
-    }
-}
-
 // One wave per (sequence, chunk); no workgroup barrier anywhere.
-template <int PREC>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void b2h_fwd_mfma(
+__global__ __launch_bounds__(64 * kWavesPerBlock) void b2h_fwd_mfma_f32(
     const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem_mfma[];
@@ -352,7 +229,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void b2h_fwd_mfma(
     if (chunk >= nchunks) return;
 
     ChunkCtx cx;
-    cx.lds = smem_mfma + (size_t)wave * kRows * Prec<PREC>::kRowBytes;
+    cx.lds = smem_mfma + (size_t)wave * kRows * Prec<PREC_F32>::kRowBytes;
     cx.lane = threadIdx.x & 63;
     cx.tcol = cx.lane & 15;
     cx.q = cx.lane >> 4;
@@ -365,7 +242,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void b2h_fwd_mfma(
     cx.fa = fa;
     cx.nvalid = T;
     if ((fa.flags & kPostMask) && fa.n_frames) cx.nvalid = fa.n_frames[cx.seq];
-    run_chunk<PREC>(cx, x + cx.seq * (int64_t)T * kInCh, mp);
+    stage_input32(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
+    layer32<0>(cx, mp); layer32<1>(cx, mp); layer32<2>(cx, mp); layer32<3>(cx, mp);
 }
 
 } // namespace b2h

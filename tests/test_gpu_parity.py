@@ -67,9 +67,11 @@ def test_golden(name, prec, cuda_device):
 
 
 @pytest.mark.parametrize("prec", ALL_PREC)
-@pytest.mark.parametrize("T", [1, 4, 15, 16, 31, 32, 47, 48, 100, 207, 208, 209, 223, 224, 225, 416, 417, 1000])
+@pytest.mark.parametrize("T", [1, 4, 15, 16, 31, 32, 47, 48, 100, 111, 112, 113, 127, 128, 191, 192, 193, 207, 208, 209,
+                               223, 224, 225, 336, 337, 384, 385, 416, 417, 1000])
 def test_lengths_vs_oracle(T, prec, cuda_device):
-    """Sequence lengths around the 16-frame tile and the 208-frame chunk edges."""
+    """Sequence lengths around the 16-frame tile and the chunk edges (112 frames in the fp32
+    MFMA kernel, 208 whole / 192 split in the persistent 16-bit kernel)."""
     rec = load_golden("cfg1_b1_t200")
     g = torch.Generator().manual_seed(T)
     x = torch.rand((5, T, 12, 2), generator=g) - 0.5
