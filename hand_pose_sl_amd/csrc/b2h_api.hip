@@ -258,9 +258,19 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             hipLaunchKernelGGL(b2h_fwd_mfma_f32, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mp32, fa);
         } else {
             // persistent kernel: one 512-thread workgroup per CU
-            const int TT = (T <= kChunkWhole16) ? kChunkWhole16 : kChunkSplit16;
+            // Chunk length: whole sequences (<= 208 frames) or 192-frame chunks keep the halo
+            // recompute at zero / 8 %.  When that leaves most of the chip's 2048 wave slots idle
+            // (small batches) shorter chunks trade halo work for parallelism; every chunking
+            // computes bit-identical frames.
+            int TT = (T <= kChunkWhole16) ? kChunkWhole16 : kChunkSplit16;
+            int64_t nch = B * ((T + TT - 1) / TT);
+            const int64_t slots = (int64_t)m->num_cus * kWaves16;
+            for (int cand : {96, 48}) {
+                if (nch * 2 >= slots || T <= cand) break;
+                TT = cand;
+                nch = B * ((T + TT - 1) / TT);
+            }
             const int cps16 = (int)((T + TT - 1) / TT);
-            const int64_t nch = B * cps16;
             const unsigned grid16 = (unsigned)std::min<int64_t>(m->num_cus, nch);
             const bool fused = fa.flags != 0;
             const bool bf = (k == B2H_KERNEL_BF16_MFMA);
