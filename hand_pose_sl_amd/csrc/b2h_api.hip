@@ -83,11 +83,11 @@ struct b2h_model {
     int cin[4], cout[4];
     // packed device weights
     DevBuf valu_w[4], valu_b[4];
-    DevBuf mf32_w[4], mbf16_w[4], mf16_w[4], m_bias[4];
-    DevBuf mbf16_all, mf16_all; // persistent 16-bit kernel: [W L0..L3 | bias L0..L3], kPacked16 bytes
+    DevBuf mf32_w[4], m_bias[4];  // exact-fp32 MFMA kernel: per-layer fragments + bias fragments
+    DevBuf mbf16_all, mf16_all;   // persistent 16-bit kernel: [W L0..L3 | bias L0..L3], kPacked16 bytes
     int num_cus = 256;
     ValuParams vp;
-    MfmaParams mp32, mpbf16, mpf16;
+    MfmaParams mp32;
     bool lds_attr_set[8] = {false, false, false, false, false, false, false, false};
 };
 
@@ -139,11 +139,13 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
     if (m->C > kMfmaWidth) return B2H_OK; // MFMA kernels: conv_channels <= 32
 
     // ---- MFMA layouts
+    std::vector<unsigned char> ab(kPacked16, 0), ah(kPacked16, 0); // LDS images of the persistent kernel
     for (int l = 0; l < 4; ++l) {
         const int MT = (l == 3) ? 3 : 2;
         auto chan = [&](int mt, int row) { return l == 3 ? last_chan_of(mt, row) : hidden_chan_of(mt, row); };
         // 16-bit: [mt][tap][lane][8]
-        std::vector<uint16_t> wb((size_t)MT * kTaps * 64 * 8), wh(wb.size());
+        uint16_t* wb = reinterpret_cast<uint16_t*>(ab.data() + kWLayerOff16[l]);
+        uint16_t* wh = reinterpret_cast<uint16_t*>(ah.data() + kWLayerOff16[l]);
         for (int mt = 0; mt < MT; ++mt)
             for (int k = 0; k < kTaps; ++k)
                 for (int lane = 0; lane < 64; ++lane)
@@ -167,31 +169,18 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
         for (int mt = 0; mt < MT; ++mt)
             for (int q = 0; q < 4; ++q)
                 for (int r = 0; r < 4; ++r) bf[(mt * 4 + q) * 4 + r] = hw.bias(l, chan(mt, 4 * q + r));
+        std::memcpy(ab.data() + kBiasOff16[l], bf.data(), bf.size() * 4);
+        std::memcpy(ah.data() + kBiasOff16[l], bf.data(), bf.size() * 4);
         int rc;
-        if ((rc = m->mbf16_w[l].upload(wb.data(), wb.size() * 2))) return rc;
-        if ((rc = m->mf16_w[l].upload(wh.data(), wh.size() * 2))) return rc;
         if ((rc = m->mf32_w[l].upload(wf.data(), wf.size() * 4))) return rc;
         if ((rc = m->m_bias[l].upload(bf.data(), bf.size() * 4))) return rc;
-        m->mpbf16.w[l] = m->mbf16_w[l].p;
-        m->mpf16.w[l] = m->mf16_w[l].p;
         m->mp32.w[l] = m->mf32_w[l].p;
-        m->mpbf16.bias[l] = m->mpf16.bias[l] = m->mp32.bias[l] = (const float*)m->m_bias[l].p;
+        m->mp32.bias[l] = (const float*)m->m_bias[l].p;
     }
-    m->mpbf16.pos_emb = m->mpf16.pos_emb = m->mp32.pos_emb = m->pos_emb;
-    {   // contiguous image the persistent kernel copies into LDS once per workgroup
-        std::vector<unsigned char> ab(kPacked16, 0), ah(kPacked16, 0);
-        for (int l = 0; l < 4; ++l) {
-            const int MT = (l == 3) ? 3 : 2;
-            const size_t wbytes = (size_t)MT * kTaps * kWFrag16, bbytes = (size_t)MT * 64;
-            HIP_TRY(hipMemcpy(ab.data() + kWLayerOff16[l], m->mbf16_w[l].p, wbytes, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(ah.data() + kWLayerOff16[l], m->mf16_w[l].p, wbytes, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(ab.data() + kBiasOff16[l], m->m_bias[l].p, bbytes, hipMemcpyDeviceToHost));
-            std::memcpy(ah.data() + kBiasOff16[l], ab.data() + kBiasOff16[l], bbytes);
-        }
-        int rc;
-        if ((rc = m->mbf16_all.upload(ab.data(), ab.size()))) return rc;
-        if ((rc = m->mf16_all.upload(ah.data(), ah.size()))) return rc;
-    }
+    m->mp32.pos_emb = m->pos_emb;
+    int rc;
+    if ((rc = m->mbf16_all.upload(ab.data(), ab.size()))) return rc;
+    if ((rc = m->mf16_all.upload(ah.data(), ah.size()))) return rc;
     return B2H_OK;
 }
 

@@ -1,0 +1,72 @@
+"""Utterance inference on the MI355X path: OpenPose JSON frames in, OpenPose JSON frames out.
+
+The working equivalent of the reference's `infer_utterance.py` (:52-111) + `steps/traintest.py`
+`infer_utterance` (:214-300) for `--model Conv --predict right_hand`:
+
+    python -m hand_pose_sl_amd.infer --data <folder of *_keypoints.json> \
+        --model-checkpoint best_model.pth --output-folder out/ [--conv-channels 30]
+        [--conv-pos-emb] [--max-frames 200] [--no-normalize] [--dif-encoding] [--precision fp32]
+
+Transforms, model and de-normalisation run as ONE fused kernel (`ConvModel.forward_fused`).
+Several utterances (sub-folders) are batched into one launch.
+"""
+import argparse
+import glob
+import os
+
+import numpy as np
+import torch
+
+from . import openpose
+from .conv_model import ConvModel
+
+
+def predict_utterances(model, utterances, max_frames=200, dif_encoding=False, normalize=True):
+    """`utterances`: list of frame lists (paths or dicts).  Returns (pred_px (U, max_frames, 21, 2)
+    numpy in pixel units, list of n_frames).  Same staging as the reference's dataset (first
+    `max_frames` frames, short utterances padded by repeating frame 0)."""
+    items = [openpose.load_utterance(u, max_frames) for u in utterances]
+    body = torch.from_numpy(np.stack([it["body_kp"] for it in items]))
+    dev = next(model.parameters()).device
+    with torch.no_grad():
+        pred = model.forward_fused(body.to(dev), dif_encoding=dif_encoding, normalize=normalize,
+                                   denormalize=normalize, mask_tail=False)
+    return pred.cpu().numpy(), [it["n_frames"] for it in items]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--data", required=True, help="folder with one utterance's frame JSONs, or with one sub-folder per utterance")
+    ap.add_argument("--model-checkpoint", required=True)
+    ap.add_argument("--output-folder", required=True)
+    ap.add_argument("--conv-channels", type=int, default=30)
+    ap.add_argument("--conv-pos-emb", action="store_true")
+    ap.add_argument("--max-frames", type=int, default=200)
+    ap.add_argument("--no-normalize", dest="normalize", action="store_false")
+    ap.add_argument("--dif-encoding", action="store_true")
+    ap.add_argument("--precision", default="fp32")
+    args = ap.parse_args(argv)
+
+    if os.path.isdir(args.output_folder):
+        raise Exception("Experiment name " + args.output_folder + " already exists.")  # infer_utterance.py:55-56
+    subs = sorted(d for d in glob.glob(os.path.join(args.data, "*")) if os.path.isdir(d))
+    folders = subs if subs else [args.data]
+    utts = [sorted(glob.glob(os.path.join(f, "*.json"))) for f in folders]
+    utts = [(f, u) for f, u in zip(folders, utts) if u]
+    if not utts:
+        raise SystemExit("no *.json frames under " + args.data)
+
+    model = ConvModel(args.conv_channels, "ReLU", pos_emb=args.conv_pos_emb, precision=args.precision)
+    model.load_state_dict(torch.load(args.model_checkpoint, map_location="cpu", weights_only=True))
+    model = model.to("cuda").eval()
+    pred, n_frames = predict_utterances(model, [u for _, u in utts], args.max_frames, args.dif_encoding,
+                                        args.normalize)
+    os.mkdir(args.output_folder)
+    for (folder, frames), p, n in zip(utts, pred, n_frames):
+        out = args.output_folder if len(utts) == 1 else os.path.join(args.output_folder, os.path.basename(folder))
+        openpose.write_predictions(frames[:n], p, out)
+    print(f"wrote {sum(n_frames)} frames of {len(utts)} utterance(s) to {args.output_folder}")
+
+
+if __name__ == "__main__":
+    main()

@@ -130,6 +130,53 @@ def transform_case(utils, hpm, name, T, n_frames, seed):
     print(f"{name}: body{tuple(body.shape)} -> pred_px{tuple(masked.shape)}")
 
 
+def openpose_case(tpd, utils, hpm, name, n_frames, max_frames, seed):
+    """The JSON inference flow of infer_utterance.py:52-111 + traintest.py:214-300 on synthetic
+    OpenPose BODY_25 frames: load_keypoints -> PoseDataset.pad/clip/to_tensor ->
+    NormalizeFixedFactor, BuildRightHandItem -> ConvModel -> x1280 -> array2open_pose."""
+    import json
+    import types
+    rng = np.random.default_rng(seed)
+
+    def flat(n):
+        kp = np.concatenate([rng.uniform(0, 1280, (n, 1)), rng.uniform(0, 720, (n, 1)),
+                             rng.uniform(0, 1, (n, 1))], axis=1)
+        return [float(round(v, 3)) for v in kp.reshape(-1)]          # OpenPose writes 3 decimals
+
+    frames = [{"version": 1.3, "people": [{"person_id": [-1], "pose_keypoints_2d": flat(25),
+                                           "face_keypoints_2d": [], "hand_left_keypoints_2d": flat(21),
+                                           "hand_right_keypoints_2d": flat(21)}]} for _ in range(n_frames)]
+    fake = types.SimpleNamespace(max_frames=max_frames)
+    item = tpd.PoseDataset.load_jsons(fake, frames[:max_frames])
+    item = tpd.PoseDataset.pad(fake, item)
+    item = tpd.PoseDataset.clip(fake, item)
+    item = tpd.PoseDataset.to_tensor(fake, item)
+    staged = {k: item[k].numpy().copy() for k in ("body_kp", "body_conf", "right_hand_kp", "right_hand_conf",
+                                                  "left_hand_kp", "left_hand_conf")}
+    for t in (utils.NormalizeFixedFactor(1280), utils.BuildRightHandItem()):
+        item = t(item)
+    torch.manual_seed(seed)
+    model = hpm.ConvModel(30, "ReLU", False).eval()
+    with torch.no_grad():
+        pred = model(item["input_kp"].unsqueeze(0))[0].contiguous()
+    pred = pred * 1280
+    pred = pred.numpy()
+    out_hands = [utils.array2open_pose(pred[i]) for i in range(min(n_frames, max_frames))]
+    rec = {k.replace(".", "_"): v.numpy() for k, v in model.state_dict().items()}
+    rec.update({"staged_" + k: v for k, v in staged.items()})
+    rec.update(pred_px=pred, meta=np.array([1, max_frames, 30, 0, seed], dtype=np.int64),
+               n_frames=np.array(n_frames), frames_json=np.array(json.dumps(frames)),
+               out_hands_json=np.array(json.dumps(out_hands)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: {n_frames} frames -> max_frames {max_frames}, {len(out_hands)} hands written")
+
+
+def _stub_io_deps():
+    """text_pose_dataset.py imports h5py at module top (absent here, unused by PoseDataset)."""
+    if "h5py" not in sys.modules:
+        sys.modules["h5py"] = types.ModuleType("h5py")
+
+
 def main():
     _stub_fairseq()
     hpm = _load(os.path.join(REF, "models", "HandPoseModels.py"), "ref_HandPoseModels")
@@ -152,6 +199,11 @@ def main():
                   keep=[0, 1, 31, 62, 63])
     # pre/post-processing
     transform_case(utils, hpm, "transforms_b6_t40", 40, [40, 1, 17, 39, 25, 8], 11)
+    # OpenPose JSON wire format + utterance staging
+    _stub_io_deps()
+    tpd = _load(os.path.join(REF, "dataloaders", "text_pose_dataset.py"), "ref_text_pose_dataset")
+    openpose_case(tpd, utils, hpm, "openpose_short_n7_m12", 7, 12, 21)
+    openpose_case(tpd, utils, hpm, "openpose_long_n30_m20", 30, 20, 22)
 
 
 if __name__ == "__main__":
