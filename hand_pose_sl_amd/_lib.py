@@ -39,6 +39,7 @@ SYMBOLS = {
                                          ctypes.c_float, _vp, ctypes.c_int, _vp]),
     "b2h_target_transform": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                             ctypes.c_float, _vp]),
+    "b2h_masked_l1": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp]),
     "b2h_model_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                       ctypes.POINTER(ctypes.c_int)]),
     "b2h_kernel_supported": (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -389,6 +389,19 @@ int b2h_target_transform(const float* body, const float* hand, float* hand_out, 
     return B2H_OK;
 }
 
+int b2h_masked_l1(const float* pred, const float* target, const int64_t* n_frames, int64_t B, int64_t T,
+                  float* per_seq, float* loss, void* stream) {
+    if (B < 1 || T < 1) return fail(B2H_ERR_SHAPE, "masked L1 needs B >= 1 and T >= 1");
+    if (B > 0x7fffffff || T > (1 << 24)) return fail(B2H_ERR_SHAPE, "shape too large");
+    if (!pred || !target || !per_seq || !loss) return fail(B2H_ERR_INVALID, "NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(b2h_masked_l1_seq_kernel, dim3((unsigned)B), dim3(256), 0, st, pred, target, n_frames, per_seq,
+                       (int)T);
+    hipLaunchKernelGGL(b2h_mean_kernel, dim3(1), dim3(256), 0, st, per_seq, loss, B);
+    HIP_TRY(hipGetLastError());
+    return B2H_OK;
+}
+
 int b2h_model_info(const b2h_model* m, int* conv_channels, int* pos_emb, int* has_weights) {
     if (!m) return fail(B2H_ERR_INVALID, "model is NULL");
     if (conv_channels) *conv_channels = m->C;

@@ -135,4 +135,39 @@ __global__ __launch_bounds__(256) void b2h_target_transform_kernel(const float* 
     }
 }
 
+// maskedPoseL1 (steps/utils.py:413-428): per sequence the mean of |pred - target| over its
+// first n_frames[i] frames x 21 joints x 2, then the mean over the batch.
+// Pass 1: one workgroup per sequence -> per_seq[i] (fixed summation order: reproducible).
+__global__ __launch_bounds__(256) void b2h_masked_l1_seq_kernel(const float* __restrict__ pred,
+                                                                const float* __restrict__ target,
+                                                                const int64_t* __restrict__ n_frames,
+                                                                float* __restrict__ per_seq, int T) {
+    __shared__ float part[4];
+    const int64_t b = blockIdx.x;
+    int64_t n = n_frames ? n_frames[b] : T;
+    n = n < 0 ? 0 : (n > T ? T : n);
+    const int64_t cnt = n * kOutCh;                       // floats of this sequence that count
+    const float2* p = reinterpret_cast<const float2*>(pred + b * (int64_t)T * kOutCh);
+    const float2* t = reinterpret_cast<const float2*>(target + b * (int64_t)T * kOutCh);
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < cnt / 2; i += 256) {
+        const float2 a = p[i], c = t[i];
+        acc += fabsf(a.x - c.x) + fabsf(a.y - c.y);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) per_seq[b] = (part[0] + part[1] + part[2] + part[3]) / (float)cnt; // 0/0 = NaN like torch
+}
+// Pass 2: one workgroup, mean of per_seq over the batch.
+__global__ __launch_bounds__(256) void b2h_mean_kernel(const float* __restrict__ v, float* __restrict__ out, int64_t n) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) acc += v[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (part[0] + part[1] + part[2] + part[3]) / (float)n;
+}
+
 } // namespace b2h

@@ -110,6 +110,15 @@ int b2h_forward_fused(b2h_model* m, const float* body, float* y, int64_t B, int6
 int b2h_target_transform(const float* body, const float* hand, float* hand_out, int64_t B,
                          int64_t T, int flags, float factor, void* stream);
 
+/* Evaluation metric of the reference: maskedPoseL1 (steps/utils.py:413-428) --
+ *   loss = mean_i( mean(|pred[i, :n_frames[i]] - target[i, :n_frames[i]]|) ),  i < B.
+ * pred, target: device fp32 (B, T, 21, 2); n_frames: device int64 (B) or NULL (= T);
+ * per_seq: device fp32 (B) scratch that receives the per-sequence means; loss: device fp32 (1).
+ * A sequence with n_frames 0 contributes NaN, as torch's mean of an empty tensor does.
+ * "Pixel distance" (L12Pixels, steps/utils.py:291-299) is loss / 21 * 1280 on the host. */
+int b2h_masked_l1(const float* pred, const float* target, const int64_t* n_frames, int64_t B,
+                  int64_t T, float* per_seq, float* loss, void* stream);
+
 /* Introspection / measurement -------------------------------------------- */
 
 /* conv_channels, pos_emb and whether weights are loaded. */

@@ -35,6 +35,8 @@ def _load():
         lib.b2h_oracle_postprocess.restype = ctypes.c_int
         lib.b2h_oracle_postprocess.argtypes = [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                ctypes.POINTER(ctypes.c_int64)]
+        lib.b2h_oracle_masked_l1.restype = ctypes.c_int
+        lib.b2h_oracle_masked_l1.argtypes = [_fp, _fp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, _fp, _fp]
         _lib = lib
     return _lib
 
@@ -125,3 +127,21 @@ def postprocess(pred, factor=1280.0, n_frames=None):
     if rc != 0:
         raise RuntimeError(f"b2h_oracle_postprocess failed: {rc}")
     return out
+
+
+def masked_l1(pred, target, lengths=None):
+    """maskedPoseL1 (steps/utils.py:413-428).  Returns (loss float32 scalar, per_seq (B,))."""
+    lib = _load()
+    pred, target = _f32(pred), _f32(target)
+    B, T = pred.shape[:2]
+    nf = None
+    if lengths is not None:
+        nfa = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
+        nf = nfa.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    per = np.empty((B,), dtype=np.float32)
+    loss = np.empty((1,), dtype=np.float32)
+    rc = lib.b2h_oracle_masked_l1(_p(pred), _p(target), nf, B, T, _p(per), _p(loss))
+    if rc != 0:
+        raise RuntimeError(f"b2h_oracle_masked_l1 failed: {rc}")
+    return loss[0], per
+

@@ -211,3 +211,29 @@ int b2h_oracle_postprocess(float* pred, int B, int T, float factor, const int64_
         }
     return 0;
 }
+
+/*
+ * maskedPoseL1.forward (steps/utils.py:413-428): per sequence the mean of |pred - target|
+ * over its first n_frames[b] frames (x 21 joints x 2), then the mean over the batch.
+ * Accumulates in double (the reference averages fp32 with torch's pairwise sums; the two
+ * agree to fp32 rounding).  per_seq (B) may be NULL.  n_frames[b] == 0 gives NaN like torch.
+ */
+int b2h_oracle_masked_l1(const float* pred, const float* target, const int64_t* n_frames, int B,
+                         int T, float* per_seq, float* loss) {
+    if (B < 1 || T < 1 || !pred || !target || !loss) return -1;
+    double total = 0.0;
+    for (int b = 0; b < B; ++b) {
+        int64_t n = n_frames ? n_frames[b] : T;
+        if (n < 0) n = 0;
+        if (n > T) n = T;
+        double acc = 0.0;
+        const size_t base = (size_t)b * T * 2 * N_HAND, cnt = (size_t)n * 2 * N_HAND;
+        for (size_t i = 0; i < cnt; ++i) acc += fabs((double)pred[base + i] - (double)target[base + i]);
+        const double mean = acc / (double)cnt; /* 0/0 -> NaN */
+        if (per_seq) per_seq[b] = (float)mean;
+        total += mean;
+    }
+    *loss = (float)(total / B);
+    return 0;
+}
+

@@ -171,6 +171,20 @@ def openpose_case(tpd, utils, hpm, name, n_frames, max_frames, seed):
     print(f"{name}: {n_frames} frames -> max_frames {max_frames}, {len(out_hands)} hands written")
 
 
+def metric_case(utils, name, B, T, lengths, seed):
+    """maskedPoseL1 + L12Pixels (steps/utils.py:413-428,291-299)."""
+    gen = torch.Generator().manual_seed(seed)
+    pred = torch.rand((B, T, 21, 2), generator=gen) - 0.5
+    tgt = torch.rand((B, T, 21, 2), generator=gen) - 0.5
+    loss = utils.maskedPoseL1()(pred, tgt, lengths)
+    per_seq = torch.stack([torch.nn.functional.l1_loss(pred[i, :n], tgt[i, :n]) for i, n in enumerate(lengths)])
+    pix = utils.L12Pixels(21, 1280)(loss)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), pred=pred.numpy(), target=tgt.numpy(),
+                        lengths=np.array(lengths, dtype=np.int64), loss=loss.numpy(), per_seq=per_seq.numpy(),
+                        pixels=pix.numpy(), meta=np.array([B, T, 0, 0, seed], dtype=np.int64))
+    print(f"{name}: loss {float(loss):.6f}  pixels {float(pix):.4f}")
+
+
 def _stub_io_deps():
     """text_pose_dataset.py imports h5py at module top (absent here, unused by PoseDataset)."""
     if "h5py" not in sys.modules:
@@ -199,6 +213,8 @@ def main():
                   keep=[0, 1, 31, 62, 63])
     # pre/post-processing
     transform_case(utils, hpm, "transforms_b6_t40", 40, [40, 1, 17, 39, 25, 8], 11)
+    # evaluation metric
+    metric_case(utils, "metric_b5_t60", 5, 60, [60, 1, 33, 59, 17], 31)
     # OpenPose JSON wire format + utterance staging
     _stub_io_deps()
     tpd = _load(os.path.join(REF, "dataloaders", "text_pose_dataset.py"), "ref_text_pose_dataset")
