@@ -172,3 +172,25 @@ def test_large_stream_properties(cuda_device):
         assert np.abs(y[idx].cpu().numpy() - ref).max() <= TOL[prec]
         assert torch.isfinite(y).all()
         del y
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f32_mfma"])
+def test_hip_graph_capture_and_replay(prec, cuda_device):
+    """The launch path does no allocation or synchronisation, so a caller can capture it
+    into a HIP graph (torch.cuda.CUDAGraph on ROCm) and replay it on fresh data."""
+    rec = load_golden("cfg1_b1_t200")
+    m = _model(rec, prec, cuda_device)
+    g = torch.Generator().manual_seed(21)
+    x_static = (torch.rand((32, 200, 12, 2), generator=g) - 0.5).to(cuda_device)
+    with torch.no_grad():
+        m(x_static)                                   # first launch sets the LDS attribute
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            y_static = m(x_static)
+        for seed in (1, 2):
+            x_new = (torch.rand((32, 200, 12, 2), generator=torch.Generator().manual_seed(seed)) - 0.5).to(cuda_device)
+            x_static.copy_(x_new)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y_static, m(x_new))
