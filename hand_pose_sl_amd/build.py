@@ -6,6 +6,7 @@ The library is a plain C-ABI shared object (include/b2h.h); it links only the
 HIP runtime.  hipcc cross-compiles without a GPU, so this runs in the build
 container; the resulting .so travels to the GPU box with the source tree.
 """
+import fcntl
 import os
 import shutil
 import subprocess
@@ -34,18 +35,29 @@ def stale():
 
 
 def build(force=False, verbose=False):
-    """Compile libb2h.so if missing or older than its sources.  Returns its path."""
+    """Compile libb2h.so if missing or older than its sources.  Returns its path.
+
+    Safe under concurrent callers (one rank per GPU all importing the package at once):
+    an exclusive file lock serialises the check-and-compile, the library is written to a
+    temporary name and renamed into place atomically."""
     if not force and not stale():
         return LIB
-    cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function",
-           "-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
-    if os.environ.get("B2H_ABLATE"):  # development: timing-only ablation builds (kernel_mfma16.h)
-        cmd.insert(1, "-DB2H_ABLATE=" + os.environ["B2H_ABLATE"])
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():      # another process built it while we waited
+                return LIB
+            tmp = f"{LIB}.tmp.{os.getpid()}"
+            cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared",
+                   "-Wall", "-Wno-unused-function", "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if os.environ.get("B2H_ABLATE"):  # development: timing-only ablation builds (kernel_mfma16.h)
+                cmd.insert(1, "-DB2H_ABLATE=" + os.environ["B2H_ABLATE"])
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

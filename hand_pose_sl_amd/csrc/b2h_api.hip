@@ -219,6 +219,15 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
                                    "HandPoseModels.py:23,78-84)");
     if (B == 0) return B2H_OK;
     if (!x || !y) return fail(B2H_ERR_INVALID, "x / y is NULL");
+    // 16-B vector loads of x rows (96 B each) and 8-B granular stores of y rows (168 B each)
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
+        return fail(B2H_ERR_INVALID, "x and y must be 16-byte aligned (hipMalloc / torch allocations are)");
+    {
+        const char* xb = reinterpret_cast<const char*>(x);
+        const char* yb = reinterpret_cast<const char*>(y);
+        const size_t xn = (size_t)B * T * kInCh * 4, yn = (size_t)B * T * kOutCh * 4;
+        if (xb < yb + yn && yb < xb + xn) return fail(B2H_ERR_INVALID, "x and y overlap");
+    }
     if ((fa.flags & kPostMask) && !fa.n_frames)
         return fail(B2H_ERR_INVALID, "B2H_POST_MASK_TAIL needs n_frames");
     const int k = resolve_kernel(m, kernel);

@@ -89,7 +89,8 @@ int b2h_load_weights(b2h_model* m, const float* w1, const float* b1, const float
  *   y : device, fp32, (B, T, 21, 2) contiguous  -- written (value-identical to
  *       the reference's non-contiguous view, :60-62)
  * T >= 1; pos_emb models require T == 100 (B2H_ERR_SHAPE, as torch.cat raises
- * in the reference, :78-84).  B == 0 is a no-op.  x and y must not overlap. */
+ * in the reference, :78-84).  B == 0 is a no-op.  x and y must be 16-byte aligned and must
+ * not overlap (B2H_ERR_INVALID otherwise). */
 int b2h_forward(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int kernel,
                 void* stream);
 

@@ -102,3 +102,17 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_concurrent_builds_do_not_race(tmp_path):
+    """Eight ranks importing the package at once (torchrun) must not corrupt libb2h.so:
+    the build is serialised by a file lock and the library is renamed into place."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); from hand_pose_sl_amd import build, _lib; "
+            "build.build(); print(_lib.load().b2h_version())" % ROOT)
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for _ in range(4)]
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err.decode()[-500:]
+        assert out.decode().strip().endswith("100")

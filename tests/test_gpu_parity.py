@@ -194,3 +194,47 @@ def test_hip_graph_capture_and_replay(prec, cuda_device):
             graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(y_static, m(x_new))
+
+
+def test_c_abi_argument_checks(cuda_device):
+    """Misaligned or overlapping buffers are refused, not silently mis-computed."""
+    import ctypes
+    from hand_pose_sl_amd import _lib
+    rec = load_golden("cfg1_b1_t200")
+    m = _model(rec, "bf16", cuda_device)
+    lib = m._ensure_handle()
+    buf = torch.zeros(4 + 200 * 24 + 200 * 42 + 64, dtype=torch.float32, device=cuda_device)
+    x, y = buf[:200 * 24], buf[200 * 24 + 8:200 * 24 + 8 + 200 * 42]
+    vp = ctypes.c_void_p
+    assert lib.b2h_forward(m._handle, vp(x.data_ptr()), vp(y.data_ptr()), 1, 200, 3, None) == _lib.OK
+    assert lib.b2h_forward(m._handle, vp(x.data_ptr() + 4), vp(y.data_ptr()), 1, 200, 3, None) == _lib.ERR_INVALID
+    assert b"aligned" in lib.b2h_last_error()
+    assert lib.b2h_forward(m._handle, vp(x.data_ptr()), vp(x.data_ptr() + 1024), 1, 200, 3, None) == _lib.ERR_INVALID
+    assert b"overlap" in lib.b2h_last_error()
+    assert lib.b2h_forward(m._handle, vp(x.data_ptr()), vp(y.data_ptr()), 1, 0, 3, None) == _lib.ERR_SHAPE
+    assert lib.b2h_forward(m._handle, vp(x.data_ptr()), vp(y.data_ptr()), 1, 200, 9, None) == _lib.ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+
+
+def test_two_streams_concurrently(cuda_device):
+    """Independent launches on two streams (each with its own output) give the same
+    results as serial launches: the library keeps no per-call device state."""
+    rec = load_golden("cfg1_b1_t200")
+    m = _model(rec, "bf16", cuda_device)
+    g = torch.Generator().manual_seed(5)
+    xa = (torch.rand((512, 200, 12, 2), generator=g) - 0.5).to(cuda_device)
+    xb = (torch.rand((512, 200, 12, 2), generator=g) - 0.5).to(cuda_device)
+    with torch.no_grad():
+        ra, rb = m(xa), m(xb)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for _ in range(5):
+            with torch.cuda.stream(s1):
+                ya = m(xa)
+            with torch.cuda.stream(s2):
+                yb = m(xb)
+            outs.append((ya, yb))
+        torch.cuda.synchronize()
+    for ya, yb in outs:
+        assert torch.equal(ya, ra) and torch.equal(yb, rb)
