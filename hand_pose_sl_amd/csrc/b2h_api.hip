@@ -15,6 +15,7 @@
 #include "b2h_common.h"
 #include "kernel_mfma.h"
 #include "kernel_mfma16.h"
+#include "kernel_tenc.h"
 #include "kernel_valu.h"
 
 using namespace b2h;
@@ -293,6 +294,182 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
 }
 
 } // namespace
+
+// ---- TransformerEnc ---------------------------------------------------------------------
+struct TencLinear {
+    DevBuf wfrag, bias;
+    int kgroups = 0, kvalid = 0, mtiles = 0, nout = 0;
+};
+
+struct b2h_tenc {
+    int nlayers = 0, max_len = 0, device = 0;
+    bool has_weights = false;
+    bool lds_attr[3] = {false, false, false};
+    DevBuf pe;
+    TencLinear in_proj, out_proj;
+    struct Layer {
+        TencLinear qkv, attn_out, ff1, ff2;
+        DevBuf g1, b1, g2, b2;
+    };
+    std::vector<Layer> layers;
+};
+
+namespace {
+
+// W (nout, k) row-major fp32 -> [mt][g][lane][4] with W[16mt + (lane&15)][16g + 4(lane>>4) + j]
+int pack_linear(TencLinear& L, const float* w, const float* b, int nout, int k) {
+    L.kvalid = k;
+    L.kgroups = (k + 15) / 16;
+    L.mtiles = (nout + 15) / 16;
+    L.nout = nout;
+    std::vector<float> wf((size_t)L.mtiles * L.kgroups * 64 * 4, 0.f), bf((size_t)L.mtiles * 16, 0.f);
+    for (int mt = 0; mt < L.mtiles; ++mt)
+        for (int g = 0; g < L.kgroups; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int o = 16 * mt + (lane & 15), kk = 16 * g + 4 * (lane >> 4) + j;
+                    if (o < nout && kk < k) wf[(((size_t)mt * L.kgroups + g) * 64 + lane) * 4 + j] = w[(size_t)o * k + kk];
+                }
+    for (int o = 0; o < nout; ++o) bf[o] = b[o];
+    int rc;
+    if ((rc = L.wfrag.upload(wf.data(), wf.size() * 4))) return rc;
+    return L.bias.upload(bf.data(), bf.size() * 4);
+}
+
+template <int EPI>
+int launch_linear(b2h_tenc* m, const TencLinear& L, const float* x, int ldx, float* y, int ldy, int64_t n,
+                  const float* res, const float* gamma, const float* beta, const float* pe, int T, hipStream_t st) {
+    LinearArgs a{x, ldx, L.kgroups, L.kvalid, (const float*)L.wfrag.p, (const float*)L.bias.p, L.mtiles, L.nout,
+                 y, ldy, n, res, gamma, beta, pe, T};
+    const size_t lds = (size_t)std::min(kLinChunkMT, L.mtiles) * L.kgroups * 1024;
+    if (lds >= 64 * 1024 && !m->lds_attr[EPI]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_linear_f32<EPI>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        m->lds_attr[EPI] = true;
+    }
+    const int64_t blocks = (n + 16 * kLinWaves - 1) / (16 * kLinWaves);
+    hipLaunchKernelGGL(b2h_linear_f32<EPI>, dim3((unsigned)blocks), dim3(64 * kLinWaves), lds, st, a);
+    return B2H_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int b2h_tenc_create(int ninp, int nhead, int nhid, int nout, int nlayers, int max_len, b2h_tenc** out) {
+    if (!out) return fail(B2H_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (ninp != kInCh || nhead != kTencHeads || nhid != kTencD || nout != kOutCh)
+        return fail(B2H_ERR_UNSUPPORTED, "TransformerEnc: only ninp=24, nhead=4, nhid=128, nout=42 "
+                                         "(infer_utterance.py:99-101) is implemented");
+    if (nlayers < 1 || nlayers > 16 || max_len < 1 || max_len > 128)
+        return fail(B2H_ERR_UNSUPPORTED, "TransformerEnc: 1 <= nlayers <= 16 and 1 <= max_len <= 128");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return fail(B2H_ERR_NO_DEVICE, "no HIP device visible (libb2h has no CPU path)");
+    b2h_tenc* m = new b2h_tenc();
+    HIP_TRY(hipGetDevice(&m->device));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, m->device));
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        delete m;
+        return fail(B2H_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", libb2h is built for gfx950 only");
+    }
+    m->nlayers = nlayers;
+    m->max_len = max_len;
+    m->layers.resize(nlayers);
+    *out = m;
+    return B2H_OK;
+}
+
+int b2h_tenc_destroy(b2h_tenc* m) {
+    delete m;
+    return B2H_OK;
+}
+
+int b2h_tenc_load_weights(b2h_tenc* m, const float* const* tensors, int count, int on_device) {
+    if (!m || !tensors) return fail(B2H_ERR_INVALID, "NULL argument");
+    if (count != 5 + 12 * m->nlayers) return fail(B2H_ERR_INVALID, "expected 5 + 12*nlayers tensors");
+    const int D = kTencD;
+    std::vector<size_t> sizes = {(size_t)m->max_len * kInCh, (size_t)D * kInCh, (size_t)D};
+    for (int l = 0; l < m->nlayers; ++l)
+        for (size_t s : {(size_t)3 * D * D, (size_t)3 * D, (size_t)D * D, (size_t)D, (size_t)D * D, (size_t)D,
+                         (size_t)D * D, (size_t)D, (size_t)D, (size_t)D, (size_t)D, (size_t)D})
+            sizes.push_back(s);
+    sizes.push_back((size_t)kOutCh * D);
+    sizes.push_back((size_t)kOutCh);
+    std::vector<std::vector<float>> h(count);
+    for (int i = 0; i < count; ++i) {
+        if (!tensors[i]) return fail(B2H_ERR_INVALID, "tensor pointer is NULL");
+        h[i].resize(sizes[i]);
+        if (on_device) HIP_TRY(hipMemcpy(h[i].data(), tensors[i], sizes[i] * 4, hipMemcpyDeviceToHost));
+        else std::memcpy(h[i].data(), tensors[i], sizes[i] * 4);
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    int rc;
+    if ((rc = m->pe.upload(h[0].data(), h[0].size() * 4))) return rc;
+    if ((rc = pack_linear(m->in_proj, h[1].data(), h[2].data(), D, kInCh))) return rc;
+    for (int l = 0; l < m->nlayers; ++l) {
+        auto& L = m->layers[l];
+        const int o = 3 + 12 * l;
+        if ((rc = pack_linear(L.qkv, h[o].data(), h[o + 1].data(), 3 * D, D))) return rc;
+        if ((rc = pack_linear(L.attn_out, h[o + 2].data(), h[o + 3].data(), D, D))) return rc;
+        if ((rc = pack_linear(L.ff1, h[o + 4].data(), h[o + 5].data(), D, D))) return rc;
+        if ((rc = pack_linear(L.ff2, h[o + 6].data(), h[o + 7].data(), D, D))) return rc;
+        if ((rc = L.g1.upload(h[o + 8].data(), D * 4))) return rc;
+        if ((rc = L.b1.upload(h[o + 9].data(), D * 4))) return rc;
+        if ((rc = L.g2.upload(h[o + 10].data(), D * 4))) return rc;
+        if ((rc = L.b2.upload(h[o + 11].data(), D * 4))) return rc;
+    }
+    const int o = 3 + 12 * m->nlayers;
+    if ((rc = pack_linear(m->out_proj, h[o].data(), h[o + 1].data(), kOutCh, D))) return rc;
+    m->has_weights = true;
+    return B2H_OK;
+}
+
+size_t b2h_tenc_workspace_bytes(const b2h_tenc* m, int64_t B, int64_t T) {
+    if (!m || B < 0 || T < 0) return 0;
+    return (size_t)B * T * (6 * kTencD) * sizeof(float); // XA, XB, OC (128 each) + QKV (384)
+}
+
+int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (!m) return fail(B2H_ERR_INVALID, "model is NULL");
+    if (!m->has_weights) return fail(B2H_ERR_NO_WEIGHTS, "b2h_tenc_forward before b2h_tenc_load_weights");
+    if (B < 0 || T < 1) return fail(B2H_ERR_SHAPE, "expected B >= 0 and T >= 1");
+    if (T > m->max_len)
+        return fail(B2H_ERR_SHAPE, "TransformerEnc: T exceeds the positional encoding's max_len (src + pe[:T], "
+                                   "HandPoseModels.py:101,167)");
+    if (B == 0) return B2H_OK;
+    const int64_t n = B * T;
+    if (B * kTencHeads > 0x7fffffff || n > ((int64_t)1 << 40)) return fail(B2H_ERR_SHAPE, "batch too large");
+    if (!x || !y || !workspace) return fail(B2H_ERR_INVALID, "NULL pointer");
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return fail(B2H_ERR_INVALID, "x and workspace must be 16-byte aligned");
+    if (workspace_bytes < b2h_tenc_workspace_bytes(m, B, T)) return fail(B2H_ERR_INVALID, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* XA = reinterpret_cast<float*>(workspace);
+    float* XB = XA + n * kTencD;
+    float* OC = XB + n * kTencD;
+    float* QKV = OC + n * kTencD;
+    const float* pe = (const float*)m->pe.p;
+    int rc;
+    // src + pe, pose2hidden_projection (HandPoseModels.py:167-169)
+    if ((rc = launch_linear<LIN_PLAIN>(m, m->in_proj, x, kInCh, XA, kTencD, n, nullptr, nullptr, nullptr, pe, (int)T, st))) return rc;
+    for (auto& L : m->layers) { // torch.nn.TransformerEncoderLayer, post-norm, ReLU
+        if ((rc = launch_linear<LIN_PLAIN>(m, L.qkv, XA, kTencD, QKV, 3 * kTencD, n, nullptr, nullptr, nullptr, nullptr, 1, st))) return rc;
+        hipLaunchKernelGGL(b2h_attn_f32, dim3((unsigned)(B * kTencHeads)), dim3(128), (size_t)T * 256, st, QKV, OC, (int)T);
+        if ((rc = launch_linear<LIN_RES_LN>(m, L.attn_out, OC, kTencD, XB, kTencD, n, XA, (const float*)L.g1.p, (const float*)L.b1.p, nullptr, 1, st))) return rc;
+        if ((rc = launch_linear<LIN_RELU>(m, L.ff1, XB, kTencD, OC, kTencD, n, nullptr, nullptr, nullptr, nullptr, 1, st))) return rc;
+        if ((rc = launch_linear<LIN_RES_LN>(m, L.ff2, OC, kTencD, XA, kTencD, n, XB, (const float*)L.g2.p, (const float*)L.b2.p, nullptr, 1, st))) return rc;
+    }
+    // hidden2pose_projection (:171)
+    if ((rc = launch_linear<LIN_PLAIN>(m, m->out_proj, XA, kTencD, y, kOutCh, n, nullptr, nullptr, nullptr, nullptr, 1, st))) return rc;
+    HIP_TRY(hipGetLastError());
+    return B2H_OK;
+}
+
+} // extern "C"
 
 extern "C" {
 

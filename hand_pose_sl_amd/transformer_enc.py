@@ -1,0 +1,120 @@
+"""Drop-in mirror of the reference's `TransformerEnc` (body2hand/src/models/HandPoseModels.py:
+118-178), the second text-free body->hand model, on libb2h's gfx950 kernels.
+
+Same constructor `TransformerEnc(ninp, nhead, nhid, nout, nlayers, dropout=0.5)` and the same
+`state_dict` (the torch.nn containers are built in the reference's order, so a seeded default
+init is identical and its checkpoints load as they are); `model(src)` with src float32
+(B, T, 12, 2) -> float32 (B, T, 21, 2).  The torch containers only hold parameters: the forward
+runs through the C ABI (`b2h_tenc_forward`).  Inference only; only the geometry the reference's
+CLIs construct (ninp=24, nhead=4, nhid=128, nout=42; infer_utterance.py:99-101) is implemented.
+"""
+import ctypes
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoidal table added to the (T, B, d_model) input; registered as buffer `pe` of shape
+    (max_len, 1, d_model) so that it is part of the state_dict like the reference's
+    (HandPoseModels.py:86-103).  pe[p, 2i] = sin(p w_i), pe[p, 2i+1] = cos(p w_i),
+    w_i = 10000^(-2i/d_model)."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        freq = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        angle = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1) * freq
+        table = torch.zeros(max_len, d_model)
+        table[:, 0::2] = torch.sin(angle)
+        table[:, 1::2] = torch.cos(angle)
+        self.register_buffer("pe", table.unsqueeze(0).transpose(0, 1))
+
+
+class TransformerEnc(nn.Module):
+    def __init__(self, ninp, nhead, nhid, nout, nlayers, dropout=0.5):
+        super().__init__()
+        self.model_type = "Transformer"
+        self.src_mask = None
+        self.pos_encoder = PositionalEncoding(ninp, dropout, max_len=100)
+        encoder_layers = nn.TransformerEncoderLayer(nhid, nhead, nhid, dropout)
+        with warnings.catch_warnings():  # torch notes that seq-first layers skip its nested-tensor path
+            warnings.simplefilter("ignore", UserWarning)
+            self.transformer_encoder = nn.TransformerEncoder(encoder_layers, nlayers)
+        self.ninp = ninp
+        self.hidden2pose_projection = nn.Linear(nhid, nout)
+        self.pose2hidden_projection = nn.Linear(ninp, nhid)
+        self._geom = (int(ninp), int(nhead), int(nhid), int(nout), int(nlayers))
+        self._handle = None
+        self._packed_key = None
+        self._workspace = None
+
+    def _tensors(self):
+        t = [self.pos_encoder.pe, self.pose2hidden_projection.weight, self.pose2hidden_projection.bias]
+        for layer in self.transformer_encoder.layers:
+            t += [layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias,
+                  layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias,
+                  layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+                  layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias]
+        return t + [self.hidden2pose_projection.weight, self.hidden2pose_projection.bias]
+
+    def _ensure_handle(self):
+        dev = self.pose2hidden_projection.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("hand_pose_sl_amd.TransformerEnc runs on an MI355X only: call model.to('cuda') "
+                               "first (there is no CPU path in the product)")
+        lib = _lib.load()
+        tensors = self._tensors()
+        key = (dev.index,) + tuple((p.data_ptr(), p._version) for p in tensors)
+        if self._handle is not None and key == self._packed_key:
+            return lib
+        with torch.cuda.device(dev):
+            if self._handle is None or self._packed_key[0] != dev.index:
+                self._free()
+                h = ctypes.c_void_p()
+                _lib.check(lib.b2h_tenc_create(*self._geom, int(self.pos_encoder.pe.shape[0]), ctypes.byref(h)))
+                self.__dict__["_handle"] = h
+            ps = [p.detach().to(torch.float32).contiguous() for p in tensors]
+            torch.cuda.current_stream(dev).synchronize()
+            arr = (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+            _lib.check(lib.b2h_tenc_load_weights(self._handle, arr, len(ps), 1))
+        self.__dict__["_packed_key"] = key
+        return lib
+
+    def _free(self):
+        if self.__dict__.get("_handle") is not None:
+            try:
+                _lib.load().b2h_tenc_destroy(self._handle)
+            except Exception:
+                pass
+            self.__dict__["_handle"] = None
+            self.__dict__["_packed_key"] = None
+
+    def __del__(self):
+        self._free()
+
+    def forward(self, src):
+        lib = self._ensure_handle()
+        if src.dim() != 4 or src.shape[2] * src.shape[3] != self.ninp:
+            raise RuntimeError(f"expected input of shape (B, T, {self.ninp // 2}, 2), got {tuple(src.shape)}")
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("hand_pose_sl_amd.TransformerEnc is inference-only: call model.eval() and wrap "
+                               "the call in torch.no_grad()")
+        dev = self.pose2hidden_projection.weight.device
+        x = src.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+        B, T = x.shape[0], x.shape[1]
+        y = torch.empty((B, T, 21, 2), dtype=torch.float32, device=dev)
+        need = lib.b2h_tenc_workspace_bytes(self._handle, B, T)
+        ws = self.__dict__.get("_workspace")
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+            self.__dict__["_workspace"] = ws
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.b2h_tenc_forward(self._handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                            B, T, ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(st)))
+        return y

@@ -120,6 +120,32 @@ int b2h_target_transform(const float* body, const float* hand, float* hand_out, 
 int b2h_masked_l1(const float* pred, const float* target, const int64_t* n_frames, int64_t B,
                   int64_t T, float* per_seq, float* loss, void* stream);
 
+/* TransformerEnc -------------------------------------------
+ * The reference's second text-free body->hand model, `TransformerEnc(ninp, nhead, nhid, nout,
+ * nlayers, dropout)` (HandPoseModels.py:118-178), as its CLIs build it: ninp = 24, nhead = 4,
+ * nhid = 128, nout = 42 (infer_utterance.py:99-101).  Inference only (dropout = identity).
+ * b2h_tenc_create accepts exactly that geometry, 1 <= nlayers <= 16, 1 <= max_len <= 128
+ * (100 in the reference, :125) and returns B2H_ERR_UNSUPPORTED for anything else. */
+typedef struct b2h_tenc b2h_tenc;
+int b2h_tenc_create(int ninp, int nhead, int nhid, int nout, int nlayers, int max_len, b2h_tenc** out);
+int b2h_tenc_destroy(b2h_tenc* m);
+/* Replaces load_state_dict.  `tensors`: 5 + 12*nlayers fp32 contiguous arrays in this order
+ * (state_dict names of the reference):
+ *   pos_encoder.pe (max_len,1,24); pose2hidden_projection.weight (128,24), .bias (128);
+ *   per layer i, transformer_encoder.layers.i.: self_attn.in_proj_weight (384,128),
+ *     self_attn.in_proj_bias (384), self_attn.out_proj.weight (128,128), self_attn.out_proj.bias,
+ *     linear1.weight (128,128), linear1.bias, linear2.weight (128,128), linear2.bias,
+ *     norm1.weight, norm1.bias, norm2.weight, norm2.bias (128 each);
+ *   hidden2pose_projection.weight (42,128), .bias (42). */
+int b2h_tenc_load_weights(b2h_tenc* m, const float* const* tensors, int count, int on_device);
+/* Bytes of device scratch b2h_tenc_forward needs for a (B, T) batch (3072 B per frame). */
+size_t b2h_tenc_workspace_bytes(const b2h_tenc* m, int64_t B, int64_t T);
+/* Replaces TransformerEnc.forward(src) (HandPoseModels.py:152-178): x (B,T,12,2) -> y (B,T,21,2),
+ * device fp32.  T <= max_len (the reference's `src + pe[:T]` raises beyond it): B2H_ERR_SHAPE.
+ * `workspace`: device memory of at least b2h_tenc_workspace_bytes(m, B, T), 16-byte aligned. */
+int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* Introspection / measurement -------------------------------------------- */
 
 /* conv_channels, pos_emb and whether weights are loaded. */

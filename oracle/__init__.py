@@ -12,3 +12,5 @@ tests/golden/make_golden.py) through tests/test_oracle.py.
 from .c_oracle import (build_oracle, forward, forward_from_state, masked_l1, postprocess,  # noqa: F401
                        preprocess)
 from .torch_port import TorchPort, torch_forward  # noqa: F401
+from .transformer_oracle import transformer_forward  # noqa: F401
+from .tenc_torch_port import TencTorchPort  # noqa: F401

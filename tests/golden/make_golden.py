@@ -185,6 +185,26 @@ def metric_case(utils, name, B, T, lengths, seed):
     print(f"{name}: loss {float(loss):.6f}  pixels {float(pix):.4f}")
 
 
+def tenc_cases(hpm):
+    """TransformerEnc (HandPoseModels.py:118-178) as the CLIs build it (infer_utterance.py:99-101).
+    One seeded model (weights stored once in tenc_weights.npz), several inputs."""
+    torch.manual_seed(41)
+    model = hpm.TransformerEnc(ninp=12 * 2, nhead=4, nhid=128, nout=21 * 2, nlayers=4, dropout=0.5).eval()
+    np.savez_compressed(os.path.join(OUT, "tenc_weights.npz"),
+                        **{"sd__" + k: v.numpy() for k, v in model.state_dict().items()})
+    rec = {}
+    for name, B, T, kind, seed in (("b2_t100", 2, 100, "u55", 1), ("b3_t37", 3, 37, "u01", 2),
+                                   ("b1_t1", 1, 1, "randn", 3), ("b5_t16", 5, 16, "randn", 4),
+                                   ("b2_t17", 2, 17, "u55", 5)):
+        x = _inputs(kind, (B, T, 12, 2), torch.Generator().manual_seed(seed))
+        with torch.no_grad():
+            y = model(x).contiguous()
+        rec["x_" + name], rec["y_" + name] = x.numpy(), y.numpy()
+        print(f"tenc {name}: x{tuple(x.shape)} -> y{tuple(y.shape)} |y|max={y.abs().max():.4f}")
+    np.savez_compressed(os.path.join(OUT, "tenc_cases.npz"), **rec)
+    print("tenc params", sum(v.numel() for v in model.parameters()))
+
+
 def _stub_io_deps():
     """text_pose_dataset.py imports h5py at module top (absent here, unused by PoseDataset)."""
     if "h5py" not in sys.modules:
@@ -213,6 +233,8 @@ def main():
                   keep=[0, 1, 31, 62, 63])
     # pre/post-processing
     transform_case(utils, hpm, "transforms_b6_t40", 40, [40, 1, 17, 39, 25, 8], 11)
+    # TransformerEnc
+    tenc_cases(hpm)
     # evaluation metric
     metric_case(utils, "metric_b5_t60", 5, 60, [60, 1, 33, 59, 17], 31)
     # OpenPose JSON wire format + utterance staging
