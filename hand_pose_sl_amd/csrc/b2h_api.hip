@@ -458,7 +458,11 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
     if ((rc = launch_linear<LIN_PLAIN>(m, m->in_proj, x, kInCh, XA, kTencD, n, nullptr, nullptr, nullptr, pe, (int)T, st))) return rc;
     for (auto& L : m->layers) { // torch.nn.TransformerEncoderLayer, post-norm, ReLU
         if ((rc = launch_linear<LIN_PLAIN>(m, L.qkv, XA, kTencD, QKV, 3 * kTencD, n, nullptr, nullptr, nullptr, nullptr, 1, st))) return rc;
-        hipLaunchKernelGGL(b2h_attn_f32, dim3((unsigned)(B * kTencHeads)), dim3(128), (size_t)T * 256, st, QKV, OC, (int)T);
+        {
+            const int nt = (int)((T + 15) / 16);
+            hipLaunchKernelGGL(b2h_attn_mfma_f32, dim3((unsigned)(B * kTencHeads)), dim3(64 * nt), (size_t)nt * 16 * kTencHd * 8,
+                               st, QKV, OC, (int)T);
+        }
         if ((rc = launch_linear<LIN_RES_LN>(m, L.attn_out, OC, kTencD, XB, kTencD, n, XA, (const float*)L.g1.p, (const float*)L.b1.p, nullptr, 1, st))) return rc;
         if ((rc = launch_linear<LIN_RELU>(m, L.ff1, XB, kTencD, OC, kTencD, n, nullptr, nullptr, nullptr, nullptr, 1, st))) return rc;
         if ((rc = launch_linear<LIN_RES_LN>(m, L.ff2, OC, kTencD, XA, kTencD, n, XB, (const float*)L.g2.p, (const float*)L.b2.p, nullptr, 1, st))) return rc;

@@ -12,8 +12,9 @@
 //            epilogue on the accumulator tile (lane = frame, registers = features):
 //            +bias, ReLU, or +residual then LayerNorm over the 128 features of a frame
 //            (32 in-lane values + two cross-lane steps), 16-B stores.
-//   attn   : thread = query frame; K and V of the (sequence, head) in LDS; online softmax
-//            over all T keys (the reference passes no mask, HandPoseModels.py:170).
+//   attn   : workgroup = (sequence, head), wave = 16 query frames; scores and P.V on the matrix
+//            cores, softmax in registers over all T keys (the reference passes no mask,
+//            HandPoseModels.py:170); see b2h_attn_mfma_f32.
 #pragma once
 #include "b2h_common.h"
 #include "kernel_mfma.h" // f32x4
@@ -145,50 +146,101 @@ __global__ __launch_bounds__(64 * kLinWaves) void b2h_linear_f32(LinearArgs a) {
     }
 }
 
-// Self-attention of one (sequence, head): softmax(q k^T) v with q pre-scaled by head_dim^-0.5
-// (torch.nn.MultiheadAttention), over all T keys, no mask (HandPoseModels.py:170).
+// Self-attention on the matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32): softmax(q k^T) v with
+// q pre-scaled by head_dim^-0.5 (torch.nn.MultiheadAttention).
 //   qkv : (B*T, 384) = [q | k | v] x 128, head h = columns h*32 .. h*32+31 of each third
-//   out : (B*T, 128), head h -> columns h*32 ..
-__global__ __launch_bounds__(128) void b2h_attn_f32(const float* __restrict__ qkv, float* __restrict__ out, int T) {
-    extern __shared__ __attribute__((aligned(16))) char smem_attn[];
-    f32x4* Ks = reinterpret_cast<f32x4*>(smem_attn);   // [T][8] float4
-    f32x4* Vs = Ks + (size_t)T * 8;
+//   out : (B*T, 128), head h -> columns h*32 ..  Workgroup = (sequence,
+// head); wave w owns query tile w (16 frames) against all key tiles:
+//   S^T[key][query] = K[key][d] . (Q[query][d] * 32^-0.5)      8 MFMAs per 16x16 tile
+//   softmax over keys: the 4*ntiles scores of a query sit in ONE lane quartet
+//                      (registers + lanes l, l^16, l^32), keys >= T masked to -inf
+//   O^T[d][query] = V^T[d][key] . P^T[key][query]: the score tile's accumulator IS the B operand
+//                      (D row 4q+r  <->  B k-index q for fixed r): no shuffle, no LDS round trip
+// K and V of the head live in LDS ([key][32] fp32, rows T..16*ntiles zero).
+constexpr int kAttnMaxTiles = 8; // T <= 128
+
+__global__ __launch_bounds__(64 * kAttnMaxTiles) void b2h_attn_mfma_f32(const float* __restrict__ qkv,
+                                                                      float* __restrict__ out, int T) {
+    extern __shared__ __attribute__((aligned(16))) char smem_attn2[];
+    float* Ks = reinterpret_cast<float*>(smem_attn2);
+    const int nt = (T + 15) >> 4;
+    float* Vs = Ks + nt * 16 * kTencHd;
     const int b = blockIdx.x / kTencHeads, h = blockIdx.x % kTencHeads;
-    const int t = threadIdx.x;
-    const float* row = qkv + ((int64_t)b * T + t) * (3 * kTencD) + h * kTencHd;
-    f32x4 qv[8];
-    if (t < T) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            qv[i] = *reinterpret_cast<const f32x4*>(row + 4 * i) * 0.17677669529663687f; // 32^-0.5
-            Ks[t * 8 + i] = *reinterpret_cast<const f32x4*>(row + kTencD + 4 * i);
-            Vs[t * 8 + i] = *reinterpret_cast<const f32x4*>(row + 2 * kTencD + 4 * i);
+    const float* base = qkv + (int64_t)b * T * (3 * kTencD) + h * kTencHd;
+    // stage K, V: (nt*16) rows x 8 float4, zero beyond T
+    for (int i = threadIdx.x; i < nt * 16 * 8; i += blockDim.x) {
+        const int t = i >> 3, c = i & 7;
+        f32x4 k4 = f32x4{0.f, 0.f, 0.f, 0.f}, v4 = k4;
+        if (t < T) {
+            k4 = *reinterpret_cast<const f32x4*>(base + (int64_t)t * (3 * kTencD) + kTencD + 4 * c);
+            v4 = *reinterpret_cast<const f32x4*>(base + (int64_t)t * (3 * kTencD) + 2 * kTencD + 4 * c);
         }
+        reinterpret_cast<f32x4*>(Ks)[i] = k4;
+        reinterpret_cast<f32x4*>(Vs)[i] = v4;
     }
     __syncthreads();
-    if (t >= T) return;
-    float mx = -INFINITY, l = 0.f;
-    f32x4 o[8];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= nt) return;
+    const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
+    const int tq = wave * 16 + col;
+    // B operand of S^T: this lane's query, d = 16g + 4q + j, pre-scaled (torch scales q, not the scores)
+    f32x4 qb[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int tk = 0; tk < T; ++tk) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x4 k4 = Ks[tk * 8 + i];
-            s += qv[i][0] * k4[0] + qv[i][1] * k4[1] + qv[i][2] * k4[2] + qv[i][3] * k4[3];
-        }
-        const float mn = fmaxf(mx, s);
-        const float scale = expf(mx - mn), p = expf(s - mn); // mx = -inf on the first key: scale = 0
-        l = l * scale + p;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = o[i] * scale + Vs[tk * 8 + i] * p;
-        mx = mn;
+    for (int g = 0; g < 2; ++g) {
+        qb[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tq < T) qb[g] = *reinterpret_cast<const f32x4*>(base + (int64_t)tq * (3 * kTencD) + 16 * g + 4 * q) * 0.17677669529663687f;
     }
-    const float inv = 1.0f / l;
-    float* orow = out + ((int64_t)b * T + t) * kTencD + h * kTencHd;
+    f32x4 sc[kAttnMaxTiles];
+    float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(orow + 4 * i) = o[i] * inv;
+    for (int kt = 0; kt < kAttnMaxTiles; ++kt) {
+        sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kt < nt) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                // A operand: key row kt*16 + col, d = 16g + 4q + j
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(Ks + (kt * 16 + col) * kTencHd + 16 * g + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j], qb[g][j], sc[kt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { // D row 4q + r = key index within the tile
+                if (kt * 16 + 4 * q + r >= T) sc[kt][r] = -INFINITY;
+                mx = fmaxf(mx, sc[kt][r]);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < kAttnMaxTiles; ++kt)
+        if (kt < nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[kt][r] = expf(sc[kt][r] - mx); // masked keys: exp(-inf) = 0
+                l += sc[kt][r];
+            }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    // O^T[d][query]: for step (kt, r) lane q supplies P^T[kt*16 + 4q + r][query] = sc[kt][r];
+    // the A operand is V[kt*16 + 4q + r][16mt + col]
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kt = 0; kt < kAttnMaxTiles; ++kt)
+        if (kt < nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* vrow = Vs + (kt * 16 + 4 * q + r) * kTencHd + col;
+                o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[0], sc[kt][r], o[0], 0, 0, 0);
+                o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[16], sc[kt][r], o[1], 0, 0, 0);
+            }
+    if (tq < T) {
+        const float inv = 1.0f / l;
+        float* orow = out + ((int64_t)b * T + tq) * kTencD + h * kTencHd + 4 * q; // D rows 16mt + 4q + r = d
+        *reinterpret_cast<f32x4*>(orow) = o[0] * inv;
+        *reinterpret_cast<f32x4*>(orow + 16) = o[1] * inv;
+    }
 }
 
 } // namespace b2h
