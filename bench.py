@@ -8,10 +8,12 @@
 A "step" is one pass of the fused four-layer kernel (ConvModel.forward,
 body2hand/src/models/HandPoseModels.py:40-64 of the reference) over this rank's
 resident shard of a synthetic keypoint stream.  Workload: BASELINE.json config 3
-(bf16 MFMA path, T = 200) fed as a sustained stream -- 65 536 sequences x 200
-frames per GPU per step (256 batches of config 3's batch=256; 3.46 GB of HBM
-traffic per step, beyond the 256 MiB Infinity Cache), sequence-sharded across
-ranks with no data-path collective (weak scaling).  The metric "hand-crops/sec"
+(bf16 MFMA path, T = 200) fed as a sustained stream -- 262 144 sequences x 200
+frames per GPU per step (1024 batches of config 3's batch=256; 13.8 GB of HBM
+traffic per step, far beyond the 256 MiB Infinity Cache; a step lasts ~3 ms so
+that the GPU's clock/power transient at the start of sustained load does not
+dominate short runs), sequence-sharded across ranks with no data-path collective
+(weak scaling).  The metric "hand-crops/sec"
 of BASELINE.json is reported as frames/s: the reference has no image crops, one
 "crop" = one frame of 12x2 body keypoints in -> 21x2 hand keypoints out
 (SURVEY.md section 0).
@@ -43,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--seqs", type=int, default=65536, help="sequences per GPU per step")
+    ap.add_argument("--seqs", type=int, default=262144, help="sequences per GPU per step")
     ap.add_argument("--frames", type=int, default=200, help="T, frames per sequence (--max-frames default, run.py:28)")
     ap.add_argument("--precision", default="bf16", choices=sorted(MFMA_PEAK_TFLOPS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,13 +134,10 @@ def main():
     S, T = args.seqs, args.frames
     torch.manual_seed(0)
     model = hps.ConvModel(30, "ReLU", False, precision=args.precision).to(dev).eval()
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    # synthetic stream shard, resident in HBM before the timed region
-    x = torch.empty((S, T, 12, 2), dtype=torch.float32, device=dev)
-    chunk = 4096
-    for i in range(0, S, chunk):
-        n = min(chunk, S - i)
-        x[i:i + n] = (torch.rand((n, T, 12, 2), generator=g) - 0.5).to(dev)
+    # synthetic stream shard U[-0.5, 0.5], generated on the device, resident in HBM before the
+    # timed region
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.rand((S, T, 12, 2), dtype=torch.float32, device=dev, generator=g).sub_(0.5)
     y = torch.empty((S, T, 21, 2), dtype=torch.float32, device=dev)
 
     def barrier():
