@@ -249,12 +249,13 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
     for (int s = 0; s < kTaps; ++s) rd[s] = lds_off<64>(lo + tcol + s - kPad + pin, q);
     int wr = lds_off<64>(lo + tcol + pout, q);
 
-    // head only: output rows [0, e) of this sequence as a buffer, lane byte offset of tile 0
+    // head only: this chunk's output rows [s, e) as a buffer (so that byte offsets stay small
+    // however long the sequence is), lane byte offset within tile 0
     __amdgpu_buffer_rsrc_t yrs;
     int yoff = 0;
-    if constexpr (L == 3) {
-        yrs = make_rsrc(yseq, g.e * (kOutCh * 4));
-        yoff = (lo + tcol) * (kOutCh * 4) + 16 * q;
+    if constexpr (L == 3) { // lo == s here
+        yrs = make_rsrc(yseq + (int64_t)lo * kOutCh, (g.e - lo) * (kOutCh * 4));
+        yoff = tcol * (kOutCh * 4) + 16 * q;
     }
     // M: the 10 (15) MFMAs of one tile on fragments already in registers.
     auto mma = [&](f32x4 (&acc)[MT], const vec8 (&Bf)[kTaps]) {
@@ -290,7 +291,7 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
             if ((B2H_ABLATE & 2) && T > 0) { asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0])); }
             else {
                 // lane (tcol,q) owns channels 16mt + 4q .. +3 of frame tau + tcol: 16 B at
-                // row offset 168 t + 64 mt + 16 q; frames >= e fall outside the descriptor
+                // row offset 168 (t - s) + 64 mt + 16 q; frames >= e fall outside the descriptor
                 const bool dead = FUSED && (tau + tcol >= nvalid); // tail mask (per lane)
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) {

@@ -239,3 +239,16 @@ def test_two_streams_concurrently(cuda_device):
         torch.cuda.synchronize()
     for ya, yb in outs:
         assert torch.equal(ya, ra) and torch.equal(yb, rb)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f32_mfma", "f32_valu"])
+def test_long_sequence(prec, cuda_device):
+    """One 5 000-frame sequence = 27 chunks (16-bit) / 45 chunks (fp32 MFMA) with halos."""
+    rec = load_golden("cfg1_b1_t200")
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand((2, 5000, 12, 2), generator=g) - 0.5
+    m = _model(rec, prec, cuda_device)
+    with torch.no_grad():
+        y = m(x.to(cuda_device)).cpu().numpy()
+    ref = oracle.forward_from_state(x.numpy(), rec["state"])
+    assert np.abs(y - ref).max() <= TOL[prec]
