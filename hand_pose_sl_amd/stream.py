@@ -88,6 +88,44 @@ class ShardedStream:
         return torch.cat(outs, dim=0)
 
     @torch.no_grad()
+    def run_pipelined(self, x_local, n_seq, chunk, root=0):
+        """Like run(gather=True), but the shard is processed in `chunk`-sequence pieces and each
+        piece is handed to root as soon as it is computed: the transfer of piece k (RCCL runs it
+        on its own stream) overlaps the kernel of piece k+1.  Returns the full (n_seq, T, 21, 2)
+        result on root, None elsewhere; bit-identical to run()."""
+        if self.world == 1:
+            return self.run_local(x_local)
+        sizes = shard_sizes(n_seq, self.world)
+        if x_local.shape[0] != sizes[self.rank]:
+            raise RuntimeError(f"rank {self.rank}: shard has {x_local.shape[0]} sequences, expected {sizes[self.rank]}")
+        chunk = max(1, int(chunk))
+
+        def peer(r):
+            return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+        reqs, keep, out = [], [], None
+        if self.rank == root:
+            T = x_local.shape[1]
+            out = torch.empty((n_seq, T, 21, 2), dtype=torch.float32, device=x_local.device)
+            for r in range(self.world):        # post every receive up front, piece by piece
+                if r == root:
+                    continue
+                lo, hi = shard_bounds(n_seq, r, self.world)
+                for a in range(lo, hi, chunk):
+                    reqs.append(dist.irecv(out[a:min(a + chunk, hi)], peer(r), group=self.group))
+        lo, hi = shard_bounds(n_seq, self.rank, self.world)
+        for a in range(0, hi - lo, chunk):
+            y = self.model(x_local[a:a + chunk]).contiguous()
+            if self.rank == root:
+                out[lo + a:lo + a + y.shape[0]].copy_(y)
+            else:
+                keep.append(y)                 # keep the buffer alive until its send completes
+                reqs.append(dist.isend(y, peer(root), group=self.group))
+        for r in reqs:
+            r.wait()
+        return out
+
+    @torch.no_grad()
     def run(self, x_local, n_seq, gather=True, root=0):
         """x_local = this rank's sequences [lo,hi) of the stream.  Returns the full
         result on root when gather=True (None on other ranks), else the local shard."""

@@ -50,6 +50,11 @@ def _worker(rank, world, port, n_seq, out_path):
             assert y is None
         y_local = stream.run(x[lo:hi], n_seq, gather=False)
         assert y_local.shape[0] == hi - lo
+        y_pipe = stream.run_pipelined(x[lo:hi], n_seq, chunk=2)      # piecewise hand-back, same result
+        if rank == 0:
+            assert torch.equal(y_pipe, y)
+        else:
+            assert y_pipe is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
