@@ -252,3 +252,21 @@ def test_long_sequence(prec, cuda_device):
         y = m(x.to(cuda_device)).cpu().numpy()
     ref = oracle.forward_from_state(x.numpy(), rec["state"])
     assert np.abs(y - ref).max() <= TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ALL_PREC)
+@pytest.mark.parametrize("shift", [1, 7, 16, 37])
+def test_time_shift_equivariance(prec, shift, cuda_device):
+    """Away from the sequence ends (+-8 frames) the model is a pure convolution: shifting the
+    input by k frames shifts the output by k frames, bit for bit -- whatever tile or chunk a
+    frame lands in (T = 500 spans three 192-frame chunks / five 112-frame chunks)."""
+    rec = load_golden("cfg1_b1_t200")
+    T = 500
+    g = torch.Generator().manual_seed(shift)
+    long = (torch.rand((2, T + shift, 12, 2), generator=g) - 0.5).to(cuda_device)
+    m = _model(rec, prec, cuda_device)
+    with torch.no_grad():
+        ya = m(long[:, :T].contiguous())            # frames 0 .. T-1
+        yb = m(long[:, shift:].contiguous())        # frames shift .. T+shift-1
+    # global frame f: ya index f, yb index f - shift; both interior for f in [shift+8, T-8)
+    assert torch.equal(ya[:, shift + 8:T - 8], yb[:, 8:T - 8 - shift])
