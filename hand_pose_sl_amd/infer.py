@@ -4,10 +4,13 @@ The working equivalent of the reference's `infer_utterance.py` (:52-111) + `step
 `infer_utterance` (:214-300) for `--model Conv --predict right_hand`:
 
     python -m hand_pose_sl_amd.infer --data <folder of *_keypoints.json> \
-        --model-checkpoint best_model.pth --output-folder out/ [--conv-channels 30]
-        [--conv-pos-emb] [--max-frames 200] [--no-normalize] [--dif-encoding] [--precision fp32]
+        --model-checkpoint best_model.pth --output-folder out/ [--model Conv|TransformerEnc]
+        [--conv-channels 30] [--conv-pos-emb] [--max-frames 200] [--no-normalize] [--dif-encoding]
+        [--precision fp32]
 
-Transforms, model and de-normalisation run as ONE fused kernel (`ConvModel.forward_fused`).
+With `--model Conv` (default) transforms, model and de-normalisation run as ONE fused kernel
+(`ConvModel.forward_fused`); with `--model TransformerEnc` (infer_utterance.py:99-101) the
+item transforms run as device elementwise ops around the transformer kernels.
 Several utterances (sub-folders) are batched into one launch.
 """
 import argparse
@@ -19,6 +22,7 @@ import torch
 
 from . import openpose
 from .conv_model import ConvModel
+from .transformer_enc import TransformerEnc
 
 
 def predict_utterances(model, utterances, max_frames=200, dif_encoding=False, normalize=True):
@@ -29,8 +33,18 @@ def predict_utterances(model, utterances, max_frames=200, dif_encoding=False, no
     body = torch.from_numpy(np.stack([it["body_kp"] for it in items]))
     dev = next(model.parameters()).device
     with torch.no_grad():
-        pred = model.forward_fused(body.to(dev), dif_encoding=dif_encoding, normalize=normalize,
-                                   denormalize=normalize, mask_tail=False)
+        if isinstance(model, ConvModel):
+            pred = model.forward_fused(body.to(dev), dif_encoding=dif_encoding, normalize=normalize,
+                                       denormalize=normalize, mask_tail=False)
+        else:  # steps/utils.py:180-210 then traintest.py:270-271, as device elementwise ops
+            x = body.to(dev)
+            if dif_encoding:
+                x = x - x[:, :, 1:2]
+            if normalize:
+                x = x / 1280
+            pred = model(x)
+            if normalize:
+                pred *= 1280
     return pred.cpu().numpy(), [it["n_frames"] for it in items]
 
 
@@ -39,6 +53,7 @@ def main(argv=None):
     ap.add_argument("--data", required=True, help="folder with one utterance's frame JSONs, or with one sub-folder per utterance")
     ap.add_argument("--model-checkpoint", required=True)
     ap.add_argument("--output-folder", required=True)
+    ap.add_argument("--model", default="Conv", choices=["Conv", "TransformerEnc"])
     ap.add_argument("--conv-channels", type=int, default=30)
     ap.add_argument("--conv-pos-emb", action="store_true")
     ap.add_argument("--max-frames", type=int, default=200)
@@ -56,7 +71,10 @@ def main(argv=None):
     if not utts:
         raise SystemExit("no *.json frames under " + args.data)
 
-    model = ConvModel(args.conv_channels, "ReLU", pos_emb=args.conv_pos_emb, precision=args.precision)
+    if args.model == "Conv":
+        model = ConvModel(args.conv_channels, "ReLU", pos_emb=args.conv_pos_emb, precision=args.precision)
+    else:  # infer_utterance.py:99-101
+        model = TransformerEnc(ninp=12 * 2, nhead=4, nhid=128, nout=21 * 2, nlayers=4)
     model.load_state_dict(torch.load(args.model_checkpoint, map_location="cpu", weights_only=True))
     model = model.to("cuda").eval()
     pred, n_frames = predict_utterances(model, [u for _, u in utts], args.max_frames, args.dif_encoding,

@@ -99,3 +99,31 @@ def test_utterance_inference_end_to_end(name, tmp_path, cuda_device):
         assert np.abs(np.array(got) - np.array(hand)).max() <= 2e-5 * 1280      # fp32 kernel, pixels
     with pytest.raises(Exception, match="already exists"):                      # infer_utterance.py:55-56
         infer.main(["--data", str(src), "--model-checkpoint", str(ckpt), "--output-folder", str(out)])
+
+
+@pytest.mark.gpu
+def test_cli_with_transformer_enc(tmp_path, cuda_device):
+    """--model TransformerEnc (infer_utterance.py:99-101): frames in, frames out, values equal the
+    oracle's transformer on the same staged, normalised input."""
+    import oracle
+    from hand_pose_sl_amd import infer
+    rec = load_golden(CASES[0])
+    frames = _frames(rec)
+    src = tmp_path / "utt"
+    src.mkdir()
+    for i, fr in enumerate(frames):
+        (src / f"utt_{i:012d}_keypoints.json").write_text(json.dumps(fr))
+    w = np.load(os.path.join(os.path.dirname(__file__), "golden", "tenc_weights.npz"))
+    state = {k[4:]: w[k] for k in w.files}
+    ckpt = tmp_path / "tenc.pth"
+    torch.save({k: torch.from_numpy(v) for k, v in state.items()}, ckpt)
+    out = tmp_path / "out"
+    infer.main(["--data", str(src), "--model", "TransformerEnc", "--model-checkpoint", str(ckpt),
+                "--output-folder", str(out), "--max-frames", str(rec["T"])])
+    item = openpose.load_utterance(frames, rec["T"])
+    ref = oracle.transformer_forward(item["body_kp"][None] / np.float32(1280), state)[0] * np.float32(1280)
+    files = sorted(os.listdir(out))
+    assert len(files) == item["n_frames"]
+    for i, f in enumerate(files):
+        got = np.array(json.load(open(out / f))["people"][0]["hand_right_keypoints_2d"]).reshape(21, 3)
+        assert np.abs(got[:, :2] - ref[i]).max() <= 2e-5 * 1280 and (got[:, 2] == 1.0).all()
