@@ -296,59 +296,62 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
 } // namespace
 
 // ---- TransformerEnc ---------------------------------------------------------------------
-struct TencLinear {
-    DevBuf wfrag, bias;
-    int kgroups = 0, kvalid = 0, mtiles = 0, nout = 0;
+// One stage blob of the chain kernel: weight fragments of <= 128 outputs + bias/gamma/beta.
+struct TencBlob {
+    DevBuf buf;
+    int mtiles = 0, kgroups = 0, nout = 0;
 };
 
 struct b2h_tenc {
     int nlayers = 0, max_len = 0, device = 0;
     bool has_weights = false;
-    bool lds_attr[3] = {false, false, false};
+    bool lds_attr = false;
     DevBuf pe;
-    TencLinear in_proj, out_proj;
+    TencBlob in_proj, out_proj;
     struct Layer {
-        TencLinear qkv, attn_out, ff1, ff2;
-        DevBuf g1, b1, g2, b2;
+        TencBlob q, k, v, attn_out, ff1, ff2;
     };
     std::vector<Layer> layers;
 };
 
 namespace {
 
-// W (nout, k) row-major fp32 -> [mt][g][lane][4] with W[16mt + (lane&15)][16g + 4(lane>>4) + j]
-int pack_linear(TencLinear& L, const float* w, const float* b, int nout, int k) {
-    L.kvalid = k;
-    L.kgroups = (k + 15) / 16;
-    L.mtiles = (nout + 15) / 16;
-    L.nout = nout;
-    std::vector<float> wf((size_t)L.mtiles * L.kgroups * 64 * 4, 0.f), bf((size_t)L.mtiles * 16, 0.f);
-    for (int mt = 0; mt < L.mtiles; ++mt)
-        for (int g = 0; g < L.kgroups; ++g)
+// rows [r0, r0 + nout) of W (*, k) row-major fp32 -> [mt][g][lane][4] with
+// W[r0 + 16mt + (lane&15)][16g + 4(lane>>4) + j], followed by bias, gamma, beta (128 each)
+int pack_blob(TencBlob& B, const float* w, const float* b, int r0, int nout, int k, const float* gamma,
+              const float* beta) {
+    B.kgroups = (k + 15) / 16;
+    B.mtiles = (nout + 15) / 16;
+    B.nout = nout;
+    const size_t nw = (size_t)B.mtiles * B.kgroups * 64 * 4;
+    std::vector<float> blob(nw + kStageParams, 0.f);
+    for (int mt = 0; mt < B.mtiles; ++mt)
+        for (int g = 0; g < B.kgroups; ++g)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 4; ++j) {
                     const int o = 16 * mt + (lane & 15), kk = 16 * g + 4 * (lane >> 4) + j;
-                    if (o < nout && kk < k) wf[(((size_t)mt * L.kgroups + g) * 64 + lane) * 4 + j] = w[(size_t)o * k + kk];
+                    if (o < nout && kk < k)
+                        blob[(((size_t)mt * B.kgroups + g) * 64 + lane) * 4 + j] = w[(size_t)(r0 + o) * k + kk];
                 }
-    for (int o = 0; o < nout; ++o) bf[o] = b[o];
-    int rc;
-    if ((rc = L.wfrag.upload(wf.data(), wf.size() * 4))) return rc;
-    return L.bias.upload(bf.data(), bf.size() * 4);
+    for (int o = 0; o < nout; ++o) blob[nw + o] = b[r0 + o];
+    if (gamma) std::memcpy(blob.data() + nw + kTencD, gamma, kTencD * 4);
+    if (beta) std::memcpy(blob.data() + nw + 2 * kTencD, beta, kTencD * 4);
+    return B.buf.upload(blob.data(), blob.size() * 4);
 }
 
-template <int EPI>
-int launch_linear(b2h_tenc* m, const TencLinear& L, const float* x, int ldx, float* y, int ldy, int64_t n,
-                  const float* res, const float* gamma, const float* beta, const float* pe, int T, hipStream_t st) {
-    LinearArgs a{x, ldx, L.kgroups, L.kvalid, (const float*)L.wfrag.p, (const float*)L.bias.p, L.mtiles, L.nout,
-                 y, ldy, n, res, gamma, beta, pe, T};
-    const size_t lds = (size_t)std::min(kLinChunkMT, L.mtiles) * L.kgroups * 1024;
-    if (lds >= 64 * 1024 && !m->lds_attr[EPI]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_linear_f32<EPI>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        m->lds_attr[EPI] = true;
+ChainStage stage_of(const TencBlob& B, int type, float* out, int ldo) {
+    return ChainStage{(const float*)B.buf.p, out, type, B.mtiles, B.kgroups, ldo, B.nout};
+}
+
+int launch_chain(b2h_tenc* m, ChainArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * kStageBlobMax * sizeof(float);
+    if (!m->lds_attr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_tenc_chain_f32),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        m->lds_attr = true;
     }
-    const int64_t blocks = (n + 16 * kLinWaves - 1) / (16 * kLinWaves);
-    hipLaunchKernelGGL(b2h_linear_f32<EPI>, dim3((unsigned)blocks), dim3(64 * kLinWaves), lds, st, a);
+    const int64_t blocks = (a.n + 16 * kLinWaves - 1) / (16 * kLinWaves);
+    hipLaunchKernelGGL(b2h_tenc_chain_f32, dim3((unsigned)blocks), dim3(64 * kLinWaves), lds, st, a);
     return B2H_OK;
 }
 
@@ -408,28 +411,26 @@ int b2h_tenc_load_weights(b2h_tenc* m, const float* const* tensors, int count, i
     HIP_TRY(hipDeviceSynchronize());
     int rc;
     if ((rc = m->pe.upload(h[0].data(), h[0].size() * 4))) return rc;
-    if ((rc = pack_linear(m->in_proj, h[1].data(), h[2].data(), D, kInCh))) return rc;
+    if ((rc = pack_blob(m->in_proj, h[1].data(), h[2].data(), 0, D, kInCh, nullptr, nullptr))) return rc;
     for (int l = 0; l < m->nlayers; ++l) {
         auto& L = m->layers[l];
         const int o = 3 + 12 * l;
-        if ((rc = pack_linear(L.qkv, h[o].data(), h[o + 1].data(), 3 * D, D))) return rc;
-        if ((rc = pack_linear(L.attn_out, h[o + 2].data(), h[o + 3].data(), D, D))) return rc;
-        if ((rc = pack_linear(L.ff1, h[o + 4].data(), h[o + 5].data(), D, D))) return rc;
-        if ((rc = pack_linear(L.ff2, h[o + 6].data(), h[o + 7].data(), D, D))) return rc;
-        if ((rc = L.g1.upload(h[o + 8].data(), D * 4))) return rc;
-        if ((rc = L.b1.upload(h[o + 9].data(), D * 4))) return rc;
-        if ((rc = L.g2.upload(h[o + 10].data(), D * 4))) return rc;
-        if ((rc = L.b2.upload(h[o + 11].data(), D * 4))) return rc;
+        if ((rc = pack_blob(L.q, h[o].data(), h[o + 1].data(), 0, D, D, nullptr, nullptr))) return rc;
+        if ((rc = pack_blob(L.k, h[o].data(), h[o + 1].data(), D, D, D, nullptr, nullptr))) return rc;
+        if ((rc = pack_blob(L.v, h[o].data(), h[o + 1].data(), 2 * D, D, D, nullptr, nullptr))) return rc;
+        if ((rc = pack_blob(L.attn_out, h[o + 2].data(), h[o + 3].data(), 0, D, D, h[o + 8].data(), h[o + 9].data()))) return rc;
+        if ((rc = pack_blob(L.ff1, h[o + 4].data(), h[o + 5].data(), 0, D, D, nullptr, nullptr))) return rc;
+        if ((rc = pack_blob(L.ff2, h[o + 6].data(), h[o + 7].data(), 0, D, D, h[o + 10].data(), h[o + 11].data()))) return rc;
     }
     const int o = 3 + 12 * m->nlayers;
-    if ((rc = pack_linear(m->out_proj, h[o].data(), h[o + 1].data(), kOutCh, D))) return rc;
+    if ((rc = pack_blob(m->out_proj, h[o].data(), h[o + 1].data(), 0, kOutCh, D, nullptr, nullptr))) return rc;
     m->has_weights = true;
     return B2H_OK;
 }
 
 size_t b2h_tenc_workspace_bytes(const b2h_tenc* m, int64_t B, int64_t T) {
     if (!m || B < 0 || T < 0) return 0;
-    return (size_t)B * T * (6 * kTencD) * sizeof(float); // XA, XB, OC (128 each) + QKV (384)
+    return (size_t)B * T * (5 * kTencD) * sizeof(float); // residual stream XA, attention output OC (128 each) + QKV (384)
 }
 
 int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T, void* workspace,
@@ -449,26 +450,49 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
     if (workspace_bytes < b2h_tenc_workspace_bytes(m, B, T)) return fail(B2H_ERR_INVALID, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* XA = reinterpret_cast<float*>(workspace);
-    float* XB = XA + n * kTencD;
-    float* OC = XB + n * kTencD;
+    float* OC = XA + n * kTencD;
     float* QKV = OC + n * kTencD;
-    const float* pe = (const float*)m->pe.p;
     int rc;
-    // src + pe, pose2hidden_projection (HandPoseModels.py:167-169)
-    if ((rc = launch_linear<LIN_PLAIN>(m, m->in_proj, x, kInCh, XA, kTencD, n, nullptr, nullptr, nullptr, pe, (int)T, st))) return rc;
-    for (auto& L : m->layers) { // torch.nn.TransformerEncoderLayer, post-norm, ReLU
-        if ((rc = launch_linear<LIN_PLAIN>(m, L.qkv, XA, kTencD, QKV, 3 * kTencD, n, nullptr, nullptr, nullptr, nullptr, 1, st))) return rc;
-        {
-            const int nt = (int)((T + 15) / 16);
-            hipLaunchKernelGGL(b2h_attn_mfma_f32, dim3((unsigned)(B * kTencHeads)), dim3(64 * nt), (size_t)nt * 16 * kTencHd * 8,
-                               st, QKV, OC, (int)T);
-        }
-        if ((rc = launch_linear<LIN_RES_LN>(m, L.attn_out, OC, kTencD, XB, kTencD, n, XA, (const float*)L.g1.p, (const float*)L.b1.p, nullptr, 1, st))) return rc;
-        if ((rc = launch_linear<LIN_RELU>(m, L.ff1, XB, kTencD, OC, kTencD, n, nullptr, nullptr, nullptr, nullptr, 1, st))) return rc;
-        if ((rc = launch_linear<LIN_RES_LN>(m, L.ff2, OC, kTencD, XA, kTencD, n, XB, (const float*)L.g2.p, (const float*)L.b2.p, nullptr, 1, st))) return rc;
+    {   // src + pe -> pose2hidden_projection (HandPoseModels.py:167-169) -> layer 0's Q, K, V
+        ChainArgs a{};
+        a.x = x; a.ldx = kInCh; a.kgroups0 = 2; a.kvalid = kInCh; a.pe = (const float*)m->pe.p; a.T = (int)T;
+        a.res = nullptr; a.n = n; a.nstages = 4;
+        a.st[0] = stage_of(m->in_proj, ST_SET, XA, kTencD);
+        a.st[1] = stage_of(m->layers[0].q, ST_STORE, QKV, 3 * kTencD);
+        a.st[2] = stage_of(m->layers[0].k, ST_STORE, QKV + kTencD, 3 * kTencD);
+        a.st[3] = stage_of(m->layers[0].v, ST_STORE, QKV + 2 * kTencD, 3 * kTencD);
+        if ((rc = launch_chain(m, a, st))) return rc;
     }
-    // hidden2pose_projection (:171)
-    if ((rc = launch_linear<LIN_PLAIN>(m, m->out_proj, XA, kTencD, y, kOutCh, n, nullptr, nullptr, nullptr, nullptr, 1, st))) return rc;
+    for (int l = 0; l < m->nlayers; ++l) { // torch.nn.TransformerEncoderLayer, post-norm, ReLU
+        auto& L = m->layers[l];
+        const int nt = (int)((T + 15) / 16);
+        const dim3 ag((unsigned)(B * kTencHeads)), ab(64 * nt);
+        const size_t alds = (size_t)nt * 16 * kTencHd * 8;
+        switch (nt) {
+#define B2H_ATTN(N) case N: hipLaunchKernelGGL(b2h_attn_mfma_f32<N>, ag, ab, alds, st, QKV, OC, (int)T); break;
+            B2H_ATTN(1) B2H_ATTN(2) B2H_ATTN(3) B2H_ATTN(4) B2H_ATTN(5) B2H_ATTN(6) B2H_ATTN(7) B2H_ATTN(8)
+#undef B2H_ATTN
+            default: return fail(B2H_ERR_SHAPE, "TransformerEnc: T > 128");
+        }
+        // out_proj +res LN1 -> linear1 ReLU -> linear2 +res LN2 -> next layer's Q,K,V | hidden2pose (:171)
+        ChainArgs a{};
+        a.x = OC; a.ldx = kTencD; a.kgroups0 = 8; a.kvalid = kTencD; a.pe = nullptr; a.T = 1;
+        a.res = XA; a.n = n;
+        a.st[0] = stage_of(L.attn_out, ST_RESLN_GLOBAL, nullptr, kTencD);
+        a.st[1] = stage_of(L.ff1, ST_RELU, nullptr, kTencD);
+        if (l + 1 < m->nlayers) {
+            a.st[2] = stage_of(L.ff2, ST_RESLN_REG, XA, kTencD); // the next layer's residual
+            a.st[3] = stage_of(m->layers[l + 1].q, ST_STORE, QKV, 3 * kTencD);
+            a.st[4] = stage_of(m->layers[l + 1].k, ST_STORE, QKV + kTencD, 3 * kTencD);
+            a.st[5] = stage_of(m->layers[l + 1].v, ST_STORE, QKV + 2 * kTencD, 3 * kTencD);
+            a.nstages = 6;
+        } else {
+            a.st[2] = stage_of(L.ff2, ST_RESLN_REG, nullptr, kTencD);
+            a.st[3] = stage_of(m->out_proj, ST_STORE, y, kOutCh);
+            a.nstages = 4;
+        }
+        if ((rc = launch_chain(m, a, st))) return rc;
+    }
     HIP_TRY(hipGetLastError());
     return B2H_OK;
 }

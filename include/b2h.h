@@ -138,7 +138,7 @@ int b2h_tenc_destroy(b2h_tenc* m);
  *     norm1.weight, norm1.bias, norm2.weight, norm2.bias (128 each);
  *   hidden2pose_projection.weight (42,128), .bias (42). */
 int b2h_tenc_load_weights(b2h_tenc* m, const float* const* tensors, int count, int on_device);
-/* Bytes of device scratch b2h_tenc_forward needs for a (B, T) batch (3072 B per frame). */
+/* Bytes of device scratch b2h_tenc_forward needs for a (B, T) batch (2560 B per frame). */
 size_t b2h_tenc_workspace_bytes(const b2h_tenc* m, int64_t B, int64_t T);
 /* Replaces TransformerEnc.forward(src) (HandPoseModels.py:152-178): x (B,T,12,2) -> y (B,T,21,2),
  * device fp32.  T <= max_len (the reference's `src + pe[:T]` raises beyond it): B2H_ERR_SHAPE.
