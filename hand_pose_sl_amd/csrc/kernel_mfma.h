@@ -19,7 +19,8 @@
 //
 // 16-bit LDS image (used by kernel_mfma16.h): 16-B chunk c of physical row P is stored at
 // chunk c ^ ((P>>1)&3) (64-B rows): conflict-free for the ds_read_b128 fragment reads at
-// every row alignment and for the ds_write_b128 write-back.
+// every row alignment and for the ds_write_b128 write-back (tools/lds_bank_check.py: x1 / x1
+// with the swizzle, x2 / x4 without).
 #pragma once
 #include "b2h_common.h"
 
