@@ -179,7 +179,7 @@ def main():
         "config": {"workload": f"BASELINE config 3 stream: ConvModel(30,'ReLU',pos_emb=False) {args.precision} "
                                f"path, {S} seq x {T} frames per GPU per step, inputs resident in HBM, "
                                f"sequence-sharded, no data-path collective",
-                   "seqs_per_gpu": S, "frames_per_seq": T, "conv_channels": 30, "kernel": model.kernel_name(),
+                   "seqs_per_gpu": S, "frames_per_seq": T, "kernel": model.kernel_name(),
                    "parallelism": f"seq-shard x{world}"},
     }
 
