@@ -121,6 +121,24 @@ class ConvModel(nn.Module):
                                        _lib.KERNELS[self.precision], ctypes.c_void_p(st)))
         return y
 
+    def forward_into(self, x, y, precision=None):
+        """Launch on the current stream with caller-owned device buffers: x (B,T,12,2) -> y (B,T,21,2),
+        both contiguous float32 on the model's device.  No allocation, no synchronisation: the
+        building block of stream pipelines (hand_pose_sl_amd.stream.HostPipeline) and HIP graphs."""
+        lib = self._ensure_handle()
+        if x.dim() != 4 or x.shape[2:] != (12, 2) or y.shape != (x.shape[0], x.shape[1], 21, 2):
+            raise RuntimeError(f"expected x (B,T,12,2) and y (B,T,21,2), got {tuple(x.shape)} and {tuple(y.shape)}")
+        dev = self._device()
+        for t in (x, y):
+            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("forward_into needs contiguous float32 tensors on the model's device")
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.b2h_forward(self._handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                       x.shape[0], x.shape[1], _lib.KERNELS[precision or self.precision],
+                                       ctypes.c_void_p(st)))
+        return y
+
     def forward_fused(self, body, n_frames=None, dif_encoding=True, normalize=True, denormalize=True,
                       mask_tail=False, factor=1280.0):
         """Raw-pixel body keypoints in, pixel-space hand keypoints out, in ONE kernel:

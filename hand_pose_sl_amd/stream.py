@@ -133,3 +133,73 @@ class ShardedStream:
         if not gather:
             return y
         return gather_to_root(y, n_seq, self.group, root)
+
+
+
+class HostPipeline:
+    """Host tensor in, host tensor out, with the PCIe copies hidden behind each other and the
+    kernel: the stream is cut into pieces of `chunk` sequences; piece k's host->device copy, piece
+    k-1's kernel and piece k-2's device->host copy run concurrently on three HIP streams over
+    `depth` device buffer pairs.  The reference's loops move each batch synchronously
+    (steps/traintest.py:354-358, :267-273); this is the MI355X-side replacement for callers whose
+    data lives in host memory.  Throughput is bounded by the device->host direction
+    (168 B/frame over PCIe), not by the kernel.
+
+    `model`: a hand_pose_sl_amd.ConvModel on a CUDA device.  Results are bit-identical to
+    `model(x.cuda()).cpu()`."""
+
+    def __init__(self, model, chunk=16384, depth=2):
+        if depth < 2:
+            raise ValueError("depth must be >= 2")
+        self.model, self.chunk, self.depth = model, int(chunk), int(depth)
+        self.dev = next(model.parameters()).device
+        if self.dev.type != "cuda":
+            raise RuntimeError("HostPipeline needs the model on a CUDA device")
+        self.s_in, self.s_run, self.s_out = (torch.cuda.Stream(self.dev) for _ in range(3))
+        self._bufs = None
+
+    def _buffers(self, T):
+        if self._bufs is None or self._bufs[0][0].shape[1] != T:
+            self._bufs = [(torch.empty((self.chunk, T, 12, 2), dtype=torch.float32, device=self.dev),
+                           torch.empty((self.chunk, T, 21, 2), dtype=torch.float32, device=self.dev))
+                          for _ in range(self.depth)]
+        return self._bufs
+
+    @torch.no_grad()
+    def run(self, x_host, out=None):
+        """x_host: (N, T, 12, 2) float32 CPU tensor (pinned memory gives asynchronous copies; pageable
+        memory still works, the runtime then stages it).  Returns (N, T, 21, 2) float32 in pinned
+        host memory (or fills `out`)."""
+        if x_host.device.type != "cpu" or x_host.dim() != 4 or x_host.shape[2:] != (12, 2):
+            raise RuntimeError(f"expected a CPU tensor of shape (N, T, 12, 2), got {tuple(x_host.shape)} on {x_host.device}")
+        x_host = x_host.to(torch.float32).contiguous()
+        N, T = x_host.shape[0], x_host.shape[1]
+        y_host = out if out is not None else torch.empty((N, T, 21, 2), dtype=torch.float32, pin_memory=True)
+        bufs = self._buffers(T)
+        done_run = [None] * self.depth   # kernel of the piece that last used the slot
+        done_out = [None] * self.depth   # device->host copy of that piece
+        caller = torch.cuda.current_stream(self.dev)
+        for s in (self.s_in, self.s_run, self.s_out):
+            s.wait_stream(caller)
+        for k, a in enumerate(range(0, N, self.chunk)):
+            n = min(self.chunk, N - a)
+            slot = k % self.depth
+            xd, yd = bufs[slot]
+            with torch.cuda.stream(self.s_in):
+                if done_run[slot] is not None:
+                    self.s_in.wait_event(done_run[slot])          # the slot's input is free again
+                xd[:n].copy_(x_host[a:a + n], non_blocking=True)
+                e_in = torch.cuda.Event(); e_in.record(self.s_in)
+            with torch.cuda.stream(self.s_run):
+                self.s_run.wait_event(e_in)
+                if done_out[slot] is not None:
+                    self.s_run.wait_event(done_out[slot])         # the slot's output has left the device
+                self.model.forward_into(xd[:n], yd[:n])
+                done_run[slot] = torch.cuda.Event(); done_run[slot].record(self.s_run)
+            with torch.cuda.stream(self.s_out):
+                self.s_out.wait_event(done_run[slot])
+                y_host[a:a + n].copy_(yd[:n], non_blocking=True)
+                done_out[slot] = torch.cuda.Event(); done_out[slot].record(self.s_out)
+        self.s_out.synchronize()
+        self.s_run.synchronize()
+        return y_host

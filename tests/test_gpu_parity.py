@@ -270,3 +270,25 @@ def test_time_shift_equivariance(prec, shift, cuda_device):
         yb = m(long[:, shift:].contiguous())        # frames shift .. T+shift-1
     # global frame f: ya index f, yb index f - shift; both interior for f in [shift+8, T-8)
     assert torch.equal(ya[:, shift + 8:T - 8], yb[:, 8:T - 8 - shift])
+
+
+@pytest.mark.parametrize("n,chunk", [(1000, 256), (777, 100), (64, 256), (513, 512)])
+def test_host_pipeline_equals_direct(n, chunk, cuda_device):
+    """H2D / kernel / D2H on three streams over double buffers: same bits as the direct call,
+    for piece counts that do and do not divide the stream, pinned and pageable input."""
+    from hand_pose_sl_amd.stream import HostPipeline
+    rec = load_golden("cfg1_b1_t200")
+    m = _model(rec, "bf16", cuda_device)
+    g = torch.Generator().manual_seed(n)
+    x = torch.rand((n, 200, 12, 2), generator=g) - 0.5
+    with torch.no_grad():
+        ref = m(x.to(cuda_device)).cpu()
+    pipe = HostPipeline(m, chunk=chunk)
+    y = pipe.run(x.pin_memory())
+    assert y.is_pinned() and torch.equal(y, ref)
+    assert torch.equal(pipe.run(x), ref)                    # pageable input
+    out = torch.empty_like(ref)
+    assert pipe.run(x, out=out) is out and torch.equal(out, ref)
+    y50 = pipe.run(x[:, :50].contiguous())                  # buffers follow a new T
+    with torch.no_grad():
+        assert torch.equal(y50, m(x[:, :50].contiguous().to(cuda_device)).cpu())
