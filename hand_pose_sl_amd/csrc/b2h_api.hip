@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -370,18 +371,16 @@ int b2h_tenc_create(int ninp, int nhead, int nhid, int nout, int nlayers, int ma
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
         return fail(B2H_ERR_NO_DEVICE, "no HIP device visible (libb2h has no CPU path)");
-    b2h_tenc* m = new b2h_tenc();
+    std::unique_ptr<b2h_tenc> m(new b2h_tenc()); // released to the caller only on success
     HIP_TRY(hipGetDevice(&m->device));
     hipDeviceProp_t p;
     HIP_TRY(hipGetDeviceProperties(&p, m->device));
-    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
-        delete m;
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
         return fail(B2H_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", libb2h is built for gfx950 only");
-    }
     m->nlayers = nlayers;
     m->max_len = max_len;
     m->layers.resize(nlayers);
-    *out = m;
+    *out = m.release();
     return B2H_OK;
 }
 
@@ -527,21 +526,19 @@ int b2h_create(int conv_channels, const char* activation, int pos_emb, b2h_model
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
         return fail(B2H_ERR_NO_DEVICE, "no HIP device visible (libb2h has no CPU path)");
-    b2h_model* m = new b2h_model();
+    std::unique_ptr<b2h_model> m(new b2h_model()); // released to the caller only on success
     HIP_TRY(hipGetDevice(&m->device));
     hipDeviceProp_t p;
     HIP_TRY(hipGetDeviceProperties(&p, m->device));
-    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0) {
-        delete m;
+    if (std::strncmp(p.gcnArchName, "gfx950", 6) != 0)
         return fail(B2H_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", libb2h is built for gfx950 only");
-    }
     m->num_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     m->C = conv_channels;
     m->pos_emb = pos_emb ? 1 : 0;
     const int C = conv_channels;
     const int cin[4] = {kInCh + m->pos_emb, C, C, C}, cout[4] = {C, C, C, kOutCh};
     for (int l = 0; l < 4; ++l) { m->cin[l] = cin[l]; m->cout[l] = cout[l]; }
-    *out = m;
+    *out = m.release();
     return B2H_OK;
 }
 
