@@ -131,6 +131,12 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_f32(const float* __rest
 // in LDS: stage s+1's blob is requested from L2 before stage s's MFMAs and written to the other
 // buffer after them; one barrier per stage.
 enum { ST_SET = 0, ST_RELU = 1, ST_RESLN_GLOBAL = 2, ST_RESLN_REG = 3, ST_STORE = 4 };
+// Development only (tools/ablate_tenc.sh): timing builds of the chain kernel with parts removed
+// -- results are wrong.  256 no LayerNorm math, 1024 no blob staging, 2048 no per-stage
+// barrier, 4096 no stores, 8192 no MFMA.
+#ifndef B2H_ABLATE
+#define B2H_ABLATE 0
+#endif
 constexpr int kChainMaxStages = 8;
 constexpr int kStageParams = 3 * kTencD;                                   // bias, gamma, beta
 constexpr int kStageBlobMax = kLinChunkMT * 8 * 64 * 4 + kStageParams;    // floats: 16384 + 384
@@ -163,9 +169,22 @@ __device__ __forceinline__ void chain_gemm(const f32x4* __restrict__ wl, int lan
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][j], cur[g][j], acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) {
+                if (B2H_ABLATE & 8192) acc[mt][j] += aw[mt][j] * cur[g][j];
+                else acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt][j], cur[g][j], acc[mt], 0, 0, 0);
+            }
     }
+}
+
+// Memory operations are buffer instructions over per-workgroup descriptors: the hardware range
+// check stands in for every lane predicate (rows past the batch, feature groups a stage does not
+// have, a missing output), so the loop has no branch around a load or store and the compiler can
+// count outstanding operations instead of draining them (with predicated global_load/store it
+// waited vmcnt(0) before the first MFMA of every stage and before every store).
+constexpr uint32_t kOob = 0x7ffffff0u; // byte offset no descriptor here reaches
+
+__device__ __forceinline__ f32x4 chain_ld(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
 }
 
 __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain_f32(ChainArgs a) {
@@ -174,29 +193,47 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain_f32(ChainArg
     f32x4* buf1 = buf0 + kStageBlobMax / 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, tcol = lane & 15, q = lane >> 4;
-    const int64_t n = ((int64_t)blockIdx.x * kLinWaves + wave) * 16 + tcol;
-    const bool valid = n < a.n;
-    constexpr int kPerThread = (kStageBlobMax / 4 + 64 * kLinWaves - 1) / (64 * kLinWaves); // float4 per thread: 9
+    constexpr int kFrames = 16 * kLinWaves, kThreads = 64 * kLinWaves;
+    const int64_t n0 = (int64_t)blockIdx.x * kFrames;               // first frame of the workgroup
+    const int rows = (int)(a.n - n0 < kFrames ? a.n - n0 : kFrames); // frames it owns
+    const int fr = wave * 16 + tcol;                                  // this lane's frame
+    constexpr int kPerThread = (kStageBlobMax / 4 + kThreads - 1) / kThreads; // float4 per thread: 9
+    static_assert(kPerThread == 9 && kThreads * 16 == 8192, "blob staging below assumes 9 x 8 KiB");
 
-    auto blob_f4 = [&](int s) { return a.st[s].mtiles * a.st[s].kgroups * 64 + kStageParams / 4; };
-    // stage 0's blob straight into buffer 0
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.st[0].blob);
-        const int cnt = blob_f4(0);
-        for (int i = threadIdx.x; i < cnt; i += 64 * kLinWaves) buf0[i] = src[i];
-    }
-    // rows entering the chain: features 16g + 4q .. +3 per k-group
-    f32x4 cur[8], resid[8];
+    auto blob_bytes = [&](int s) { return (a.st[s].mtiles * a.st[s].kgroups * 64 + kStageParams / 4) * 16; };
+    auto fetch_blob = [&](f32x4 (&w)[kPerThread], const float* blob, int bytes) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(blob, (B2H_ABLATE & 1024) ? 0 : bytes);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        cur[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        resid[g] = cur[g];
-        const int k0 = 16 * g + 4 * q;
-        if (g < a.kgroups0 && valid && k0 < a.kvalid) {
-            cur[g] = *reinterpret_cast<const f32x4*>(a.x + n * a.ldx + k0);
-            if (a.pe) cur[g] += *reinterpret_cast<const f32x4*>(a.pe + (n % a.T) * a.kvalid + k0);
+        for (int u = 0; u < kPerThread; ++u)
+            w[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)threadIdx.x * 16, u * 8192, 0));
+    };
+    auto put_blob = [&](f32x4* dst, const f32x4 (&w)[kPerThread]) {
+#pragma unroll
+        for (int u = 0; u < kPerThread - 1; ++u) dst[threadIdx.x + u * kThreads] = w[u];
+        if (threadIdx.x + (kPerThread - 1) * kThreads < kStageBlobMax / 4)
+            dst[threadIdx.x + (kPerThread - 1) * kThreads] = w[kPerThread - 1];
+    };
+
+    f32x4 wreg[kPerThread];
+    fetch_blob(wreg, a.st[0].blob, blob_bytes(0));
+    // rows entering the chain (features 16g + 4q .. +3 per k-group), the positional encoding
+    // added to them (front launch), and the residual rows of a leading ST_RESLN_GLOBAL stage
+    f32x4 cur[8], resid[8];
+    {
+        const __amdgpu_buffer_rsrc_t xrs = make_rsrc(a.x + n0 * a.ldx, rows * a.ldx * 4);
+        const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pe, a.pe ? a.T * a.kvalid * 4 : 0);
+        const __amdgpu_buffer_rsrc_t rrs = make_rsrc(a.res ? a.res + n0 * kTencD : nullptr, a.res ? rows * kTencD * 4 : 0);
+        const uint32_t pos = (uint32_t)((n0 + fr) % (a.T > 0 ? a.T : 1));
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int k0 = 16 * g + 4 * q;
+            const bool have = g < a.kgroups0 && k0 < a.kvalid;
+            cur[g] = chain_ld(xrs, have ? (uint32_t)(fr * a.ldx + k0) * 4u : kOob);
+            cur[g] += chain_ld(prs, have ? (pos * (uint32_t)a.kvalid + k0) * 4u : kOob);
+            resid[g] = chain_ld(rrs, (uint32_t)(fr * kTencD + k0) * 4u);
         }
     }
+    put_blob(buf0, wreg);
     __syncthreads();
 
 #pragma unroll 1
@@ -205,35 +242,27 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain_f32(ChainArg
         f32x4* wl = (s & 1) ? buf1 : buf0;
         f32x4* wn = (s & 1) ? buf0 : buf1;
         const float* prm = reinterpret_cast<const float*>(wl + st.mtiles * st.kgroups * 64);
-        // accumulators start from the bias (LDS) plus the residual (HBM or registers)
+        // the next stage's blob is requested now and lands under this stage's MFMAs
+        const bool more = s + 1 < a.nstages;
+        fetch_blob(wreg, a.st[more ? s + 1 : s].blob, more ? blob_bytes(s + 1) : 0);
+        // accumulators start from the bias plus the residual (ST_RESLN_GLOBAL, only valid as
+        // stage 0, finds the rows read on entry in `resid`)
+        const bool addres = st.type == ST_RESLN_GLOBAL || st.type == ST_RESLN_REG;
         f32x4 acc[8];
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             acc[mt] = *reinterpret_cast<const f32x4*>(prm + 16 * (mt < st.mtiles ? mt : 0) + 4 * q);
-            if (st.type == ST_RESLN_GLOBAL && valid)
-                acc[mt] += *reinterpret_cast<const f32x4*>(a.res + n * kTencD + 16 * mt + 4 * q);
-            if (st.type == ST_RESLN_REG) acc[mt] += resid[mt];
+            if (addres) acc[mt] += resid[mt];
         }
-        // request the next stage's blob AFTER the residual rows (so that waiting for those is a
-        // counted wait that leaves these loads in flight); it lands under this stage's MFMAs
-        f32x4 wreg[kPerThread];
-        const bool more = s + 1 < a.nstages;
-        const int ncnt = more ? blob_f4(s + 1) : 0;
-        {
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.st[more ? s + 1 : s].blob);
-#pragma unroll
-            for (int u = 0; u < kPerThread; ++u) {
-                const int i = threadIdx.x + u * 64 * kLinWaves;
-                wreg[u] = (i < ncnt) ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        // the GEMM, branch-free for the three shapes the model has; eight independent accumulator
-        // chains interleaved, fragment reads free to run ahead
+        // the GEMM, branch-free for the three shapes the model has
         if (st.kgroups == 8 && st.mtiles == 8) chain_gemm<8, 8>(wl, lane, cur, acc);
         else if (st.kgroups == 2) chain_gemm<2, 8>(wl, lane, cur, acc);
         else chain_gemm<8, 3>(wl, lane, cur, acc);
+        // next blob into the other buffer (free since the previous barrier), before this stage's
+        // stores are issued: the wait for it then covers nothing younger
+        put_blob(wn, wreg);
         // epilogue
-        if (st.type == ST_RESLN_GLOBAL || st.type == ST_RESLN_REG) {
+        if (addres && !(B2H_ABLATE & 256)) {
             float sum = 0.f;
 #pragma unroll
             for (int m = 0; m < 8; ++m) sum += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
@@ -264,34 +293,32 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain_f32(ChainArg
             for (int m = 0; m < 8; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cur[m][r] = fmaxf(acc[m][r], 0.f);
-        } else if (st.type == ST_SET) {
+        } else if (st.type == ST_SET || (B2H_ABLATE & 256)) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) { cur[m] = acc[m]; resid[m] = acc[m]; }
         }
-        if (st.out && valid) { // ST_STORE: the accumulators; otherwise a copy of the stage's result
+        // ST_STORE writes the accumulators, other types an optional copy of the stage's result;
+        // no output = an empty descriptor.  Rows are nout floats wide: whole float4 where they fit
+        // and the two-float tail of the 42-wide head (nout is 128 or 42).
+        {
+            const bool on = st.out != nullptr && !(B2H_ABLATE & 4096);
+            const __amdgpu_buffer_rsrc_t ors = make_rsrc(on ? st.out + n0 * st.ldo : nullptr, on ? rows * st.ldo * 4 : 0);
+            const bool raw = st.type == ST_STORE;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                if (m < st.mtiles) {
-                    const f32x4 v = (st.type == ST_STORE) ? acc[m] : cur[m];
-                    const int o0 = 16 * m + 4 * q;
-                    float* yr = st.out + n * st.ldo + o0;
-                    if (o0 + 3 < st.nout && (st.ldo & 3) == 0) {
-                        *reinterpret_cast<f32x4*>(yr) = v;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (o0 + r < st.nout) yr[r] = v[r];
-                    }
+                const f32x4 v = raw ? acc[m] : cur[m];
+                const int o0 = 16 * m + 4 * q;
+                const uint32_t off = (uint32_t)(fr * st.ldo + o0) * 4u;
+                const bool whole = m < st.mtiles && o0 + 3 < st.nout;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (int)(whole ? off : kOob), 0, 0);
+                if (m == 2) { // the only M-tile a 42-wide row ends in
+                    const bool tail = !whole && m < st.mtiles && o0 + 1 < st.nout;
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}, ors,
+                                                          (int)(tail ? off : kOob), 0, 0);
                 }
             }
         }
-        // next stage's blob into the other buffer; everyone is done with it since the previous barrier
-#pragma unroll
-        for (int u = 0; u < kPerThread; ++u) {
-            const int i = threadIdx.x + u * 64 * kLinWaves;
-            if (i < ncnt) wn[i] = wreg[u];
-        }
-        __syncthreads();
+        if (!(B2H_ABLATE & 2048)) __syncthreads();
     }
 }
 

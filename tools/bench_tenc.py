@@ -12,9 +12,10 @@ torch.manual_seed(0)
 m = hps.TransformerEnc(24, 4, 128, 42, 4).to(dev).eval()
 state = {k: v.detach().cpu() for k, v in m.state_dict().items()}
 FLOP = lambda T: 2 * (24 * 128 + 4 * (128 * 384 + 3 * 128 * 128) + 128 * 42) + 4 * 4 * T * 32 * 2 * 2
+QUICK = "--quick" in sys.argv   # one large batch, no CPU leg (tools/ablate_tenc.sh)
 out = {"device": torch.cuda.get_device_name(0), "runs": []}
 with torch.no_grad():
-    for (B, T) in ((64, 100), (4096, 100), (32768, 100), (32768, 50)):
+    for (B, T) in (((32768, 100),) if QUICK else ((64, 100), (4096, 100), (32768, 100), (32768, 50))):
         x = (torch.rand((B, T, 12, 2)) - 0.5).to(dev)
         for _ in range(3): y = m(x)
         torch.cuda.synchronize()
@@ -27,6 +28,8 @@ with torch.no_grad():
         fps = B * T / (ms * 1e-3)
         out["runs"].append({"B": B, "T": T, "ms": ms, "frames_per_s": fps, "tflops_fp32": fps * FLOP(T) / 1e12,
                             "frac_of_fp32_mfma_peak_157": fps * FLOP(T) / 157.3e12})
+    if QUICK:
+        print(json.dumps(out)); sys.exit(0)
     # CPU port + parity on a bounded sample
     port = oracle.TencTorchPort({k: v.numpy() for k, v in state.items()})
     xs = torch.rand((256, 100, 12, 2)) - 0.5
