@@ -466,7 +466,7 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
         auto& L = m->layers[l];
         const int nt = (int)((T + 15) / 16);
         const dim3 ag((unsigned)(B * kTencHeads)), ab(64 * nt);
-        const size_t alds = (size_t)nt * 16 * kTencHd * 8;
+        const size_t alds = (size_t)nt * 16 * kAttnRow * 8; // K and V, padded rows
         switch (nt) {
 #define B2H_ATTN(N) case N: hipLaunchKernelGGL(b2h_attn_mfma_f32<N>, ag, ab, alds, st, QKV, OC, (int)T); break;
             B2H_ATTN(1) B2H_ATTN(2) B2H_ATTN(3) B2H_ATTN(4) B2H_ATTN(5) B2H_ATTN(6) B2H_ATTN(7) B2H_ATTN(8)

@@ -12,9 +12,15 @@
 // Per forward: 1 front chain (src + pe -> pose2hidden -> Q,K,V) and per layer 1 attention + 1
 // chain launch; only the residual stream, the attention output and Q,K,V cross HBM (2.5 KB per
 // frame of caller-provided workspace).
+//
+// Both kernels address global memory with buffer instructions over per-workgroup descriptors:
+// the hardware range check replaces lane predicates, which keeps every s_waitcnt a counted one.
+// On gfx950 fp32 MFMA and VALU work do not overlap on a SIMD (tools/mfma_bench.hip), so there is
+// no attempt to hide epilogues under MFMAs: the bound is their sum.
 #pragma once
 #include "b2h_common.h"
-#include "kernel_mfma.h" // f32x4
+#include "kernel_mfma.h"   // f32x4
+#include "kernel_mfma16.h" // make_rsrc, u32x4
 
 namespace b2h {
 
@@ -34,59 +40,64 @@ constexpr int kLinChunkMT = 8;   // M-tiles (x16 features) of weights staged in 
 //                      (registers + lanes l, l^16, l^32), keys >= T masked to -inf
 //   O^T[d][query] = V^T[d][key] . P^T[key][query]: the score tile's accumulator IS the B operand
 //                      (D row 4q+r  <->  B k-index q for fixed r): no shuffle, no LDS round trip
-// K and V of the head live in LDS ([key][32] fp32, rows T..16*ntiles zero).
+// K and V of the head live in LDS as [key][kAttnRow] fp32 with kAttnRow = 36: the 4-float pad
+// spreads the 16 key rows of a fragment read (ds_read_b128, K) and the 4 row groups of a V column
+// read (ds_read_b32) over all banks (a 32-float row puts them on the same ones).  Rows T..16*NT
+// are zero: every global access is a buffer instruction over the sequence's rows, whose range
+// check returns 0 past T and drops stores, so nothing is predicated and all loads of the
+// workgroup are in flight together.
 constexpr int kAttnMaxTiles = 8; // T <= 128
+constexpr int kAttnRow = 36;
 
 template <int NT> // number of 16-frame tiles = ceil(T / 16): compile-time so that the loops are branch-free
 __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_f32(const float* __restrict__ qkv,
                                                           float* __restrict__ out, int T) {
     extern __shared__ __attribute__((aligned(16))) char smem_attn2[];
     float* Ks = reinterpret_cast<float*>(smem_attn2);
-    constexpr int nt = NT;
-    float* Vs = Ks + nt * 16 * kTencHd;
+    float* Vs = Ks + NT * 16 * kAttnRow;
     const int b = blockIdx.x / kTencHeads, h = blockIdx.x % kTencHeads;
-    const float* base = qkv + (int64_t)b * T * (3 * kTencD) + h * kTencHd;
-    // stage K, V: (nt*16) rows x 8 float4, zero beyond T
-    for (int i = threadIdx.x; i < nt * 16 * 8; i += blockDim.x) {
-        const int t = i >> 3, c = i & 7;
-        f32x4 k4 = f32x4{0.f, 0.f, 0.f, 0.f}, v4 = k4;
-        if (t < T) {
-            k4 = *reinterpret_cast<const f32x4*>(base + (int64_t)t * (3 * kTencD) + kTencD + 4 * c);
-            v4 = *reinterpret_cast<const f32x4*>(base + (int64_t)t * (3 * kTencD) + 2 * kTencD + 4 * c);
-        }
-        reinterpret_cast<f32x4*>(Ks)[i] = k4;
-        reinterpret_cast<f32x4*>(Vs)[i] = v4;
-    }
-    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (int64_t)b * T * (3 * kTencD), T * 3 * kTencD * 4);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave >= nt) return;
     const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
     const int tq = wave * 16 + col;
-    // B operand of S^T: this lane's query, d = 16g + 4q + j, pre-scaled (torch scales q, not the scores)
-    f32x4 qb[2];
+    // K, V rows of the head: NT*16 rows x 8 float4 = two per thread each; and this lane's query
+    f32x4 k4[2], v4[2], qb[2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        qb[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (tq < T) qb[g] = *reinterpret_cast<const f32x4*>(base + (int64_t)tq * (3 * kTencD) + 16 * g + 4 * q) * 0.17677669529663687f;
+    for (int it = 0; it < 2; ++it) {
+        const int i = threadIdx.x + it * 64 * NT, t = i >> 3, c = i & 7;
+        const int off = (t * 3 * kTencD + h * kTencHd + 4 * c) * 4;
+        k4[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, kTencD * 4, 0));
+        v4[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 2 * kTencD * 4, 0));
     }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) // B operand of S^T: d = 16g + 4q + j
+        qb[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rs, (tq * 3 * kTencD + h * kTencHd + 16 * g + 4 * q) * 4, 0, 0));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = threadIdx.x + it * 64 * NT, t = i >> 3, c = i & 7;
+        *reinterpret_cast<f32x4*>(Ks + t * kAttnRow + 4 * c) = k4[it];
+        *reinterpret_cast<f32x4*>(Vs + t * kAttnRow + 4 * c) = v4[it];
+    }
+    qb[0] *= 0.17677669529663687f; // pre-scaled query (torch scales q, not the scores)
+    qb[1] *= 0.17677669529663687f;
+    __syncthreads();
     f32x4 sc[NT];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
         sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                // A operand: key row kt*16 + col, d = 16g + 4q + j
-                const f32x4 ka = *reinterpret_cast<const f32x4*>(Ks + (kt * 16 + col) * kTencHd + 16 * g + 4 * q);
+        for (int g = 0; g < 2; ++g) {
+            // A operand: key row kt*16 + col, d = 16g + 4q + j
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(Ks + (kt * 16 + col) * kAttnRow + 16 * g + 4 * q);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j], qb[g][j], sc[kt], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j], qb[g][j], sc[kt], 0, 0, 0);
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { // D row 4q + r = key index within the tile
-                if (kt * 16 + 4 * q + r >= T) sc[kt][r] = -INFINITY;
-                mx = fmaxf(mx, sc[kt][r]);
-            }
+        for (int r = 0; r < 4; ++r) { // D row 4q + r = key index within the tile
+            if (kt * 16 + 4 * q + r >= T) sc[kt][r] = -INFINITY;
+            mx = fmaxf(mx, sc[kt][r]);
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -95,10 +106,10 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_f32(const float* __rest
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                sc[kt][r] = expf(sc[kt][r] - mx); // masked keys: exp(-inf) = 0
-                l += sc[kt][r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            sc[kt][r] = expf(sc[kt][r] - mx); // masked keys: exp(-inf) = 0
+            l += sc[kt][r];
+        }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     // O^T[d][query]: for step (kt, r) lane q supplies P^T[kt*16 + 4q + r][query] = sc[kt][r];
@@ -107,17 +118,17 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_f32(const float* __rest
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* vrow = Vs + (kt * 16 + 4 * q + r) * kTencHd + col;
-                o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[0], sc[kt][r], o[0], 0, 0, 0);
-                o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[16], sc[kt][r], o[1], 0, 0, 0);
-            }
-    if (tq < T) {
-        const float inv = 1.0f / l;
-        float* orow = out + ((int64_t)b * T + tq) * kTencD + h * kTencHd + 4 * q; // D rows 16mt + 4q + r = d
-        *reinterpret_cast<f32x4*>(orow) = o[0] * inv;
-        *reinterpret_cast<f32x4*>(orow + 16) = o[1] * inv;
-    }
+        for (int r = 0; r < 4; ++r) {
+            const float* vrow = Vs + (kt * 16 + 4 * q + r) * kAttnRow + col;
+            o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[0], sc[kt][r], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[16], sc[kt][r], o[1], 0, 0, 0);
+        }
+    // D rows 16mt + 4q + r = d; queries >= T fall outside the descriptor
+    const float inv = 1.0f / l;
+    const __amdgpu_buffer_rsrc_t ors = make_rsrc(out + (int64_t)b * T * kTencD, T * kTencD * 4);
+    const int ooff = (tq * kTencD + h * kTencHd + 4 * q) * 4;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[0] * inv), ors, ooff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[1] * inv), ors, ooff, 64, 0);
 }
 
 // ---- per-frame chain ---------------------------------------------------------------------
