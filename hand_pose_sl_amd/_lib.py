@@ -42,6 +42,7 @@ SYMBOLS = {
     "b2h_masked_l1": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp]),
     "b2h_tenc_create": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.POINTER(_vp)]),
     "b2h_tenc_destroy": (ctypes.c_int, [_vp]),
+    "b2h_tenc_set_kernel": (ctypes.c_int, [_vp, ctypes.c_int]),
     "b2h_tenc_load_weights": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int]),
     "b2h_tenc_workspace_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int64, ctypes.c_int64]),
     "b2h_tenc_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_size_t, _vp]),

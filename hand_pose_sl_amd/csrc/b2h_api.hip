@@ -299,14 +299,16 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
 // ---- TransformerEnc ---------------------------------------------------------------------
 // One stage blob of the chain kernel: weight fragments of <= 128 outputs + bias/gamma/beta.
 struct TencBlob {
-    DevBuf buf;
-    int mtiles = 0, kgroups = 0, nout = 0;
+    DevBuf buf;   // fp32 fragments (k-groups of 16)
+    DevBuf buf16; // f16 hi + lo fragments (k-groups of 32), B2H_TENC_F16X3
+    int mtiles = 0, kgroups = 0, kgroups32 = 0, nout = 0;
 };
 
 struct b2h_tenc {
     int nlayers = 0, max_len = 0, device = 0;
     bool has_weights = false;
     bool lds_attr = false;
+    int kernel = B2H_TENC_F32;
     DevBuf pe;
     TencBlob in_proj, out_proj;
     struct Layer {
@@ -337,22 +339,52 @@ int pack_blob(TencBlob& B, const float* w, const float* b, int r0, int nout, int
     for (int o = 0; o < nout; ++o) blob[nw + o] = b[r0 + o];
     if (gamma) std::memcpy(blob.data() + nw + kTencD, gamma, kTencD * 4);
     if (beta) std::memcpy(blob.data() + nw + 2 * kTencD, beta, kTencD * 4);
-    return B.buf.upload(blob.data(), blob.size() * 4);
+    int rc = B.buf.upload(blob.data(), blob.size() * 4);
+    if (rc) return rc;
+    // f16 hi/lo fragments for v_mfma_f32_16x16x32_f16: [part][mt][g][lane][8] with k-slot (g, q, j)
+    // = input feature 32g + 16(j>>2) + 4q + (j&3) (kernel_tenc.h), then the same fp32 parameters
+    B.kgroups32 = (k + 31) / 32;
+    const size_t nh = (size_t)B.mtiles * B.kgroups32 * 64 * 8; // halves per part
+    std::vector<_Float16> frag(2 * nh, (_Float16)0.f);
+    for (int mt = 0; mt < B.mtiles; ++mt)
+        for (int g = 0; g < B.kgroups32; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int o = 16 * mt + (lane & 15), kk = 32 * g + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+                    if (o < nout && kk < k) {
+                        const float x = w[(size_t)(r0 + o) * k + kk];
+                        const _Float16 hi = (_Float16)x;
+                        const size_t at = (((size_t)mt * B.kgroups32 + g) * 64 + lane) * 8 + j;
+                        frag[at] = hi;
+                        frag[nh + at] = (_Float16)(x - (float)hi);
+                    }
+                }
+    std::vector<char> blob16(2 * nh * 2 + kStageParams * 4);
+    std::memcpy(blob16.data(), frag.data(), 2 * nh * 2);
+    std::memcpy(blob16.data() + 2 * nh * 2, blob.data() + nw, kStageParams * 4);
+    return B.buf16.upload(blob16.data(), blob16.size());
 }
 
-ChainStage stage_of(const TencBlob& B, int type, float* out, int ldo) {
-    return ChainStage{(const float*)B.buf.p, out, type, B.mtiles, B.kgroups, ldo, B.nout};
+ChainStage stage_of(const b2h_tenc* m, const TencBlob& B, int type, float* out, int ldo) {
+    if (m->kernel == B2H_TENC_F16X3)
+        return ChainStage{(const float*)B.buf16.p, out, type, B.mtiles, B.kgroups32, ldo, B.nout, 2 * B.mtiles * B.kgroups32 * 64};
+    return ChainStage{(const float*)B.buf.p, out, type, B.mtiles, B.kgroups, ldo, B.nout, B.mtiles * B.kgroups * 64};
 }
 
 int launch_chain(b2h_tenc* m, ChainArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * kStageBlobMax * sizeof(float);
     if (!m->lds_attr) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_tenc_chain_f32),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_tenc_chain<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_tenc_chain<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         m->lds_attr = true;
     }
     const int64_t blocks = (a.n + 16 * kLinWaves - 1) / (16 * kLinWaves);
-    hipLaunchKernelGGL(b2h_tenc_chain_f32, dim3((unsigned)blocks), dim3(64 * kLinWaves), lds, st, a);
+    if (m->kernel == B2H_TENC_F16X3)
+        hipLaunchKernelGGL(b2h_tenc_chain<true>, dim3((unsigned)blocks), dim3(64 * kLinWaves), lds, st, a);
+    else
+        hipLaunchKernelGGL(b2h_tenc_chain<false>, dim3((unsigned)blocks), dim3(64 * kLinWaves), lds, st, a);
     return B2H_OK;
 }
 
@@ -386,6 +418,13 @@ int b2h_tenc_create(int ninp, int nhead, int nhid, int nout, int nlayers, int ma
 
 int b2h_tenc_destroy(b2h_tenc* m) {
     delete m;
+    return B2H_OK;
+}
+
+int b2h_tenc_set_kernel(b2h_tenc* m, int kernel) {
+    if (!m) return fail(B2H_ERR_INVALID, "model is NULL");
+    if (kernel != B2H_TENC_F32 && kernel != B2H_TENC_F16X3) return fail(B2H_ERR_INVALID, "unknown TransformerEnc kernel");
+    m->kernel = kernel;
     return B2H_OK;
 }
 
@@ -456,10 +495,10 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
         ChainArgs a{};
         a.x = x; a.ldx = kInCh; a.kgroups0 = 2; a.kvalid = kInCh; a.pe = (const float*)m->pe.p; a.T = (int)T;
         a.res = nullptr; a.n = n; a.nstages = 4;
-        a.st[0] = stage_of(m->in_proj, ST_SET, XA, kTencD);
-        a.st[1] = stage_of(m->layers[0].q, ST_STORE, QKV, 3 * kTencD);
-        a.st[2] = stage_of(m->layers[0].k, ST_STORE, QKV + kTencD, 3 * kTencD);
-        a.st[3] = stage_of(m->layers[0].v, ST_STORE, QKV + 2 * kTencD, 3 * kTencD);
+        a.st[0] = stage_of(m, m->in_proj, ST_SET, XA, kTencD);
+        a.st[1] = stage_of(m, m->layers[0].q, ST_STORE, QKV, 3 * kTencD);
+        a.st[2] = stage_of(m, m->layers[0].k, ST_STORE, QKV + kTencD, 3 * kTencD);
+        a.st[3] = stage_of(m, m->layers[0].v, ST_STORE, QKV + 2 * kTencD, 3 * kTencD);
         if ((rc = launch_chain(m, a, st))) return rc;
     }
     for (int l = 0; l < m->nlayers; ++l) { // torch.nn.TransformerEncoderLayer, post-norm, ReLU
@@ -477,17 +516,17 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
         ChainArgs a{};
         a.x = OC; a.ldx = kTencD; a.kgroups0 = 8; a.kvalid = kTencD; a.pe = nullptr; a.T = 1;
         a.res = XA; a.n = n;
-        a.st[0] = stage_of(L.attn_out, ST_RESLN_GLOBAL, nullptr, kTencD);
-        a.st[1] = stage_of(L.ff1, ST_RELU, nullptr, kTencD);
+        a.st[0] = stage_of(m, L.attn_out, ST_RESLN_GLOBAL, nullptr, kTencD);
+        a.st[1] = stage_of(m, L.ff1, ST_RELU, nullptr, kTencD);
         if (l + 1 < m->nlayers) {
-            a.st[2] = stage_of(L.ff2, ST_RESLN_REG, XA, kTencD); // the next layer's residual
-            a.st[3] = stage_of(m->layers[l + 1].q, ST_STORE, QKV, 3 * kTencD);
-            a.st[4] = stage_of(m->layers[l + 1].k, ST_STORE, QKV + kTencD, 3 * kTencD);
-            a.st[5] = stage_of(m->layers[l + 1].v, ST_STORE, QKV + 2 * kTencD, 3 * kTencD);
+            a.st[2] = stage_of(m, L.ff2, ST_RESLN_REG, XA, kTencD); // the next layer's residual
+            a.st[3] = stage_of(m, m->layers[l + 1].q, ST_STORE, QKV, 3 * kTencD);
+            a.st[4] = stage_of(m, m->layers[l + 1].k, ST_STORE, QKV + kTencD, 3 * kTencD);
+            a.st[5] = stage_of(m, m->layers[l + 1].v, ST_STORE, QKV + 2 * kTencD, 3 * kTencD);
             a.nstages = 6;
         } else {
-            a.st[2] = stage_of(L.ff2, ST_RESLN_REG, nullptr, kTencD);
-            a.st[3] = stage_of(m->out_proj, ST_STORE, y, kOutCh);
+            a.st[2] = stage_of(m, L.ff2, ST_RESLN_REG, nullptr, kTencD);
+            a.st[3] = stage_of(m, m->out_proj, ST_STORE, y, kOutCh);
             a.nstages = 4;
         }
         if ((rc = launch_chain(m, a, st))) return rc;

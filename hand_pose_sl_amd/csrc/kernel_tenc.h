@@ -153,9 +153,10 @@ constexpr int kStageParams = 3 * kTencD;                                   // bi
 constexpr int kStageBlobMax = kLinChunkMT * 8 * 64 * 4 + kStageParams;    // floats: 16384 + 384
 
 struct ChainStage {
-    const float* blob;   // [mtiles*kgroups*64 float4 weight fragments][bias 128][gamma 128][beta 128]
+    const float* blob;   // [wf4 x 16 B of weight fragments][bias 128][gamma 128][beta 128]
     float* out;          // ST_STORE: destination; other types: optional copy of the stage result (or nullptr)
     int type, mtiles, kgroups, ldo, nout;
+    int wf4;             // fp32: mtiles*kgroups*64 (k-groups of 16); f16x3: 2*mtiles*kgroups*64 (k-groups of 32, hi + lo)
 };
 struct ChainArgs {
     const float* x;      // (N, ldx) rows entering the chain
@@ -187,6 +188,51 @@ __device__ __forceinline__ void chain_gemm(const f32x4* __restrict__ wl, int lan
     }
 }
 
+// ---- 3 x f16 split operands (B2H_TENC_F16X3) ---------------------------------------------------
+// x = hi + lo with hi = f16(x), lo = f16(x - hi) carries 22 significant bits, and
+//     W.x  ~=  Whi.xhi + Whi.xlo + Wlo.xhi          (the dropped Wlo.xlo term is ~2^-22 relative)
+// is three v_mfma_f32_16x16x32_f16 (fp32 accumulate) at 16x the fp32 matrix rate each: fp32-grade
+// results (max error of the golden model vs fp64: 1.2e-6, the same as the fp32 kernel) for 3/16 of
+// the matrix cycles, valid while |activation| < 65504 (f16 range).
+// The accumulator -> operand identity of the fp32 chain carries over: k-slot (g, q, j) of the
+// 32-wide k-group g holds feature 32g + 16(j>>2) + 4q + (j&3), i.e. lane (frame, q) packs its own
+// accumulator tiles 2g (j < 4) and 2g+1 (j >= 4); the host packs the weights in the same slot order.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void chain_split(const f32x4 (&v)[8], f16x8 (&bh)[4], f16x8 (&bl)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = v[2 * g + (j >> 2)][j & 3];
+            const _Float16 hi = (_Float16)x;
+            bh[g][j] = hi;
+            bl[g][j] = (_Float16)(x - (float)hi);
+        }
+}
+
+template <int KG, int MT> // blob: [hi: mt][g][lane] f16x8, then [lo] the same
+__device__ __forceinline__ void chain_gemm_h3(const f32x4* __restrict__ wl, int lane, const f16x8 (&bh)[4],
+                                              const f16x8 (&bl)[4], f32x4 (&acc)[8]) {
+    const f16x8* whi = reinterpret_cast<const f16x8*>(wl);
+    const f16x8* wlo = whi + MT * KG * 64;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        f16x8 ah[MT], al[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            ah[mt] = whi[(mt * KG + g) * 64 + lane];
+            al[mt] = wlo[(mt * KG + g) * 64 + lane];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh[g], acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl[g], acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[g], acc[mt], 0, 0, 0);
+    }
+}
+
 // Memory operations are buffer instructions over per-workgroup descriptors: the hardware range
 // check stands in for every lane predicate (rows past the batch, feature groups a stage does not
 // have, a missing output), so the loop has no branch around a load or store and the compiler can
@@ -198,7 +244,8 @@ __device__ __forceinline__ f32x4 chain_ld(__amdgpu_buffer_rsrc_t rs, uint32_t of
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
 }
 
-__global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain_f32(ChainArgs a) {
+template <bool H3> // false: fp32 operands (v_mfma_f32_16x16x4_f32); true: 3 x f16 split
+__global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_chain[];
     f32x4* buf0 = reinterpret_cast<f32x4*>(smem_chain);
     f32x4* buf1 = buf0 + kStageBlobMax / 4;
@@ -211,7 +258,7 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain_f32(ChainArg
     constexpr int kPerThread = (kStageBlobMax / 4 + kThreads - 1) / kThreads; // float4 per thread: 9
     static_assert(kPerThread == 9 && kThreads * 16 == 8192, "blob staging below assumes 9 x 8 KiB");
 
-    auto blob_bytes = [&](int s) { return (a.st[s].mtiles * a.st[s].kgroups * 64 + kStageParams / 4) * 16; };
+    auto blob_bytes = [&](int s) { return (a.st[s].wf4 + kStageParams / 4) * 16; };
     auto fetch_blob = [&](f32x4 (&w)[kPerThread], const float* blob, int bytes) {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(blob, (B2H_ABLATE & 1024) ? 0 : bytes);
 #pragma unroll
@@ -244,6 +291,8 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain_f32(ChainArg
             resid[g] = chain_ld(rrs, (uint32_t)(fr * kTencD + k0) * 4u);
         }
     }
+    f16x8 bh[4], bl[4]; // H3: the GEMM operand, split from `cur`
+    if constexpr (H3) chain_split(cur, bh, bl);
     put_blob(buf0, wreg);
     __syncthreads();
 
@@ -252,7 +301,7 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain_f32(ChainArg
         const ChainStage st = a.st[s];
         f32x4* wl = (s & 1) ? buf1 : buf0;
         f32x4* wn = (s & 1) ? buf0 : buf1;
-        const float* prm = reinterpret_cast<const float*>(wl + st.mtiles * st.kgroups * 64);
+        const float* prm = reinterpret_cast<const float*>(wl + st.wf4);
         // the next stage's blob is requested now and lands under this stage's MFMAs
         const bool more = s + 1 < a.nstages;
         fetch_blob(wreg, a.st[more ? s + 1 : s].blob, more ? blob_bytes(s + 1) : 0);
@@ -266,9 +315,15 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain_f32(ChainArg
             if (addres) acc[mt] += resid[mt];
         }
         // the GEMM, branch-free for the three shapes the model has
-        if (st.kgroups == 8 && st.mtiles == 8) chain_gemm<8, 8>(wl, lane, cur, acc);
-        else if (st.kgroups == 2) chain_gemm<2, 8>(wl, lane, cur, acc);
-        else chain_gemm<8, 3>(wl, lane, cur, acc);
+        if constexpr (H3) {
+            if (st.kgroups == 4 && st.mtiles == 8) chain_gemm_h3<4, 8>(wl, lane, bh, bl, acc);
+            else if (st.kgroups == 1) chain_gemm_h3<1, 8>(wl, lane, bh, bl, acc);
+            else chain_gemm_h3<4, 3>(wl, lane, bh, bl, acc);
+        } else {
+            if (st.kgroups == 8 && st.mtiles == 8) chain_gemm<8, 8>(wl, lane, cur, acc);
+            else if (st.kgroups == 2) chain_gemm<2, 8>(wl, lane, cur, acc);
+            else chain_gemm<8, 3>(wl, lane, cur, acc);
+        }
         // next blob into the other buffer (free since the previous barrier), before this stage's
         // stores are issued: the wait for it then covers nothing younger
         put_blob(wn, wreg);
@@ -307,6 +362,9 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain_f32(ChainArg
         } else if (st.type == ST_SET || (B2H_ABLATE & 256)) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) { cur[m] = acc[m]; resid[m] = acc[m]; }
+        }
+        if constexpr (H3) {
+            if (st.type != ST_STORE) chain_split(cur, bh, bl); // ST_STORE leaves the operand as it is
         }
         // ST_STORE writes the accumulators, other types an optional copy of the stage's result;
         // no output = an empty descriptor.  Rows are nout floats wide: whole float4 where they fit

@@ -35,9 +35,20 @@ class PositionalEncoding(nn.Module):
         self.register_buffer("pe", table.unsqueeze(0).transpose(0, 1))
 
 
+TENC_KERNELS = {"fp32": 0, "f16x3": 1}   # b2h_tenc_kernel (include/b2h.h)
+
+
 class TransformerEnc(nn.Module):
-    def __init__(self, ninp, nhead, nhid, nout, nlayers, dropout=0.5):
+    """`precision` (not in the reference; keyword only): "fp32" = fp32 operands on the matrix cores
+    (default); "f16x3" = every Linear operand split into f16 hi + lo, three f16 MFMAs per product
+    with fp32 accumulation: fp32-grade error at 3/16 of the matrix cycles, for activations and
+    weights inside the f16 range (|x| < 65504)."""
+
+    def __init__(self, ninp, nhead, nhid, nout, nlayers, dropout=0.5, *, precision="fp32"):
         super().__init__()
+        if precision not in TENC_KERNELS:
+            raise ValueError(f"precision must be one of {sorted(TENC_KERNELS)}, got {precision!r}")
+        self.precision = precision
         self.model_type = "Transformer"
         self.src_mask = None
         self.pos_encoder = PositionalEncoding(ninp, dropout, max_len=100)
@@ -115,6 +126,7 @@ class TransformerEnc(nn.Module):
             self.__dict__["_workspace"] = ws
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.b2h_tenc_set_kernel(self._handle, TENC_KERNELS[self.precision]))
             _lib.check(lib.b2h_tenc_forward(self._handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
                                             B, T, ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(st)))
         return y

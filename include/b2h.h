@@ -127,8 +127,17 @@ int b2h_masked_l1(const float* pred, const float* target, const int64_t* n_frame
  * b2h_tenc_create accepts exactly that geometry, 1 <= nlayers <= 16, 1 <= max_len <= 128
  * (100 in the reference, :125) and returns B2H_ERR_UNSUPPORTED for anything else. */
 typedef struct b2h_tenc b2h_tenc;
+/* Arithmetic of the Linear layers (attention, softmax and LayerNorm are fp32 in both):
+ *   B2H_TENC_F32   fp32 operands on v_mfma_f32_16x16x4_f32 (default);
+ *   B2H_TENC_F16X3 every operand split into f16 hi + lo, three v_mfma_f32_16x16x32_f16 per product
+ *                  (hi.hi + hi.lo + lo.hi, fp32 accumulate): fp32-grade error (22 significant
+ *                  bits per operand) at 3/16 of the matrix cycles, valid while every activation
+ *                  and weight is below 65504 in magnitude (f16 range). */
+typedef enum b2h_tenc_kernel { B2H_TENC_F32 = 0, B2H_TENC_F16X3 = 1 } b2h_tenc_kernel;
 int b2h_tenc_create(int ninp, int nhead, int nhid, int nout, int nlayers, int max_len, b2h_tenc** out);
 int b2h_tenc_destroy(b2h_tenc* m);
+/* Selects the kernel for later b2h_tenc_forward calls (no reload of the weights needed). */
+int b2h_tenc_set_kernel(b2h_tenc* m, int kernel);
 /* Replaces load_state_dict.  `tensors`: 5 + 12*nlayers fp32 contiguous arrays in this order
  * (state_dict names of the reference):
  *   pos_encoder.pe (max_len,1,24); pose2hidden_projection.weight (128,24), .bias (128);

@@ -1,6 +1,8 @@
 """TransformerEnc: numpy oracle and the Python mirror against vectors from
-the reference's class (CPU); the HIP path against both (GPU).  Tolerance: exact-fp32 kernels,
-|y| up to 2.4 after four LayerNorm-ed layers -> 2e-5 max-abs (measured ~2e-6)."""
+the reference's class (CPU); the HIP path against both (GPU).  Tolerance: |y| up to 2.4 after
+four LayerNorm-ed layers -> 2e-5 max-abs for BOTH kernels (measured ~2e-6): "fp32" computes in
+fp32 throughout, "f16x3" splits every Linear operand into f16 hi + lo (22 significant bits, three
+f16 MFMAs per product) and is held to the same bar -- it is a cheaper fp32, not a lower precision."""
 import os
 
 import numpy as np
@@ -12,6 +14,7 @@ import oracle
 from conftest import GOLDEN
 
 CASES = ["b2_t100", "b3_t37", "b1_t1", "b5_t16", "b2_t17"]
+PRECISIONS = ["fp32", "f16x3"]
 TOL = 2e-5
 
 
@@ -51,17 +54,18 @@ def test_mirror_state_dict_and_seeded_init_equal_reference():
             m.eval()(torch.zeros(1, 4, 12, 2))
 
 
-def _gpu_model(dev):
+def _gpu_model(dev, precision="fp32"):
     state, cases = _load()
-    m = hps.TransformerEnc(24, 4, 128, 42, 4)
+    m = hps.TransformerEnc(24, 4, 128, 42, 4, precision=precision)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     return m.to(dev).eval(), state, cases
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", CASES)
-def test_hip_matches_reference(name, cuda_device):
-    m, state, cases = _gpu_model(cuda_device)
+def test_hip_matches_reference(name, precision, cuda_device):
+    m, state, cases = _gpu_model(cuda_device, precision)
     x, y = cases[name]
     with torch.no_grad():
         out = m(torch.from_numpy(x))                       # host tensor accepted, like ConvModel
@@ -70,8 +74,9 @@ def test_hip_matches_reference(name, cuda_device):
 
 
 @pytest.mark.gpu
-def test_hip_batch_independence_lengths_and_errors(cuda_device):
-    m, state, _ = _gpu_model(cuda_device)
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_hip_batch_independence_lengths_and_errors(precision, cuda_device):
+    m, state, _ = _gpu_model(cuda_device, precision)
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for T in (1, 2, 15, 16, 17, 31, 33, 64, 99, 100):
@@ -90,6 +95,8 @@ def test_hip_batch_independence_lengths_and_errors(cuda_device):
             m(torch.zeros((1, 101, 12, 2)))
         with pytest.raises(RuntimeError):
             m(torch.zeros((1, 5, 11, 2)))
+    with pytest.raises(ValueError, match="precision"):
+        hps.TransformerEnc(24, 4, 128, 42, 4, precision="bf16")
     with pytest.raises(RuntimeError, match="nhid|ninp|implemented"):
         bad = hps.TransformerEnc(24, 4, 64, 42, 2).to(cuda_device).eval()
         with torch.no_grad():

@@ -9,11 +9,12 @@ import oracle
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-m = hps.TransformerEnc(24, 4, 128, 42, 4).to(dev).eval()
+PREC = next((a.split("=")[1] for a in sys.argv if a.startswith("--precision=")), "fp32")
+m = hps.TransformerEnc(24, 4, 128, 42, 4, precision=PREC).to(dev).eval()
 state = {k: v.detach().cpu() for k, v in m.state_dict().items()}
 FLOP = lambda T: 2 * (24 * 128 + 4 * (128 * 384 + 3 * 128 * 128) + 128 * 42) + 4 * 4 * T * 32 * 2 * 2
 QUICK = "--quick" in sys.argv   # one large batch, no CPU leg (tools/ablate_tenc.sh)
-out = {"device": torch.cuda.get_device_name(0), "runs": []}
+out = {"device": torch.cuda.get_device_name(0), "precision": PREC, "runs": []}
 with torch.no_grad():
     for (B, T) in (((32768, 100),) if QUICK else ((64, 100), (4096, 100), (32768, 100), (32768, 50))):
         x = (torch.rand((B, T, 12, 2)) - 0.5).to(dev)
