@@ -505,9 +505,16 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
         auto& L = m->layers[l];
         const int nt = (int)((T + 15) / 16);
         const dim3 ag((unsigned)(B * kTencHeads)), ab(64 * nt);
-        const size_t alds = (size_t)nt * 16 * kAttnRow * 8; // K and V, padded rows
+        const bool h3 = m->kernel == B2H_TENC_F16X3;
+        // fp32: K and V rows padded to kAttnRow floats; f16x3: K hi/lo [keys][32] + V^T hi/lo [32][kAttnVtRow]
+        const size_t alds = h3 ? ((size_t)2 * nt * 16 * kTencHd + (size_t)2 * kTencHd * kAttnVtRow) * 2
+                               : (size_t)nt * 16 * kAttnRow * 8;
         switch (nt) {
-#define B2H_ATTN(N) case N: hipLaunchKernelGGL(b2h_attn_mfma_f32<N>, ag, ab, alds, st, QKV, OC, (int)T); break;
+#define B2H_ATTN(N)                                                                                   \
+    case N:                                                                                           \
+        if (h3) hipLaunchKernelGGL(b2h_attn_mfma_h3<N>, ag, ab, alds, st, QKV, OC, (int)T);            \
+        else hipLaunchKernelGGL(b2h_attn_mfma_f32<N>, ag, ab, alds, st, QKV, OC, (int)T);              \
+        break;
             B2H_ATTN(1) B2H_ATTN(2) B2H_ATTN(3) B2H_ATTN(4) B2H_ATTN(5) B2H_ATTN(6) B2H_ATTN(7) B2H_ATTN(8)
 #undef B2H_ATTN
             default: return fail(B2H_ERR_SHAPE, "TransformerEnc: T > 128");

@@ -24,6 +24,8 @@
 
 namespace b2h {
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 constexpr int kTencD = 128;      // nhid (d_model and feed-forward width in the reference's CLIs)
 constexpr int kTencHeads = 4;
 constexpr int kTencHd = 32;      // head dim
@@ -131,6 +133,134 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_f32(const float* __rest
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[1] * inv), ors, ooff, 64, 0);
 }
 
+// Self-attention with 3 x f16 split operands (B2H_TENC_F16X3; the split itself: see the chain's
+// f16x3 section below).  Same workgroup / wave mapping and softmax as b2h_attn_mfma_f32; both
+// products run on v_mfma_f32_16x16x32_f16 as hi.hi + hi.lo + lo.hi with fp32 accumulation:
+//   S^T tile = K[16 keys][32 dims] . Q^T           one k-step (k = dims): A from LDS rows of K
+//              (f16 hi / lo, 64 B per key), B = this lane's query dims 8q .. 8q+7
+//   O^T      = V^T[32 dims][keys] . P^T            k = keys, 32 per step: the lane's score
+//              registers of key tiles 2s (j < 4) and 2s+1 (j >= 4) ARE the B operand when k-slot
+//              (s, q, j) means key 32s + 16(j>>2) + 4q + (j&3); V^T is stored in LDS with its keys
+//              in that slot order, so an A fragment is one 16-byte read.
+constexpr int kAttnVtRow = 136; // halves per V^T row: 128 key slots + 8 (rows 4 banks apart)
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_h3(const float* __restrict__ qkv, float* __restrict__ out, int T) {
+    extern __shared__ __attribute__((aligned(16))) char smem_attn3[];
+    constexpr int KS = (NT + 1) / 2;                       // k-steps of 32 keys
+    _Float16* Kh = reinterpret_cast<_Float16*>(smem_attn3); // [NT*16 keys][32 dims]
+    _Float16* Kl = Kh + NT * 16 * kTencHd;
+    _Float16* Vh = Kl + NT * 16 * kTencHd;                  // [32 dims][kAttnVtRow key slots]
+    _Float16* Vl = Vh + kTencHd * kAttnVtRow;
+    const int b = blockIdx.x / kTencHeads, h = blockIdx.x % kTencHeads;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv + (int64_t)b * T * (3 * kTencD), T * 3 * kTencD * 4);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
+    const int tq = wave * 16 + col;
+    f32x4 k4[2], v4[2], q4[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = threadIdx.x + it * 64 * NT, t = i >> 3, c = i & 7;
+        const int off = (t * 3 * kTencD + h * kTencHd + 4 * c) * 4;
+        k4[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, kTencD * 4, 0));
+        v4[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 2 * kTencD * 4, 0));
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) // this lane's query, dims 8q + 4g .. +3
+        q4[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rs, (tq * 3 * kTencD + h * kTencHd + 8 * q + 4 * g) * 4, 0, 0));
+    if (KS * 32 > NT * 16) { // odd NT: the last k-step's upper 16 key slots have no writer
+        for (int i = threadIdx.x; i < kTencHd * 16; i += 64 * NT) {
+            const int d = i >> 4, p = (KS - 1) * 32 + 8 * ((i >> 2) & 3) + 4 + (i & 3);
+            Vh[d * kAttnVtRow + p] = (_Float16)0.f;
+            Vl[d * kAttnVtRow + p] = (_Float16)0.f;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = threadIdx.x + it * 64 * NT, t = i >> 3, c = i & 7;
+        // key t -> slot: k-step t>>5, then 8*((t>>2)&3) + 4*((t>>4)&1) + (t&3)
+        const int p = (t & ~31) + 8 * ((t >> 2) & 3) + 4 * ((t >> 4) & 1) + (t & 3);
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 kh, kl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const _Float16 a = (_Float16)k4[it][e];
+            kh[e] = a;
+            kl[e] = (_Float16)(k4[it][e] - (float)a);
+            const _Float16 vv = (_Float16)v4[it][e];
+            Vh[(4 * c + e) * kAttnVtRow + p] = vv;
+            Vl[(4 * c + e) * kAttnVtRow + p] = (_Float16)(v4[it][e] - (float)vv);
+        }
+        *reinterpret_cast<f16x4*>(Kh + t * kTencHd + 4 * c) = kh;
+        *reinterpret_cast<f16x4*>(Kl + t * kTencHd + 4 * c) = kl;
+    }
+    f16x8 qh, ql; // B operand of S^T, pre-scaled (torch scales q, not the scores)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = q4[j >> 2][j & 3] * 0.17677669529663687f;
+        const _Float16 a = (_Float16)x;
+        qh[j] = a;
+        ql[j] = (_Float16)(x - (float)a);
+    }
+    __syncthreads();
+    f32x4 sc[2 * KS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(Kh + (kt * 16 + col) * kTencHd + 8 * q);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(Kl + (kt * 16 + col) * kTencHd + 8 * q);
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qh, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ql, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qh, a, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { // D row 4q + r = key index within the tile
+            if (kt * 16 + 4 * q + r >= T) a[r] = -INFINITY;
+            mx = fmaxf(mx, a[r]);
+        }
+        sc[kt] = a;
+    }
+    if (2 * KS > NT) sc[2 * KS - 1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2 * KS; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[kt][r] = expf(sc[kt][r] - mx); // masked keys: exp(-inf) = 0
+            l += sc[kt][r];
+        }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        f16x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = sc[2 * s + (j >> 2)][j & 3];
+            const _Float16 a = (_Float16)x;
+            ph[j] = a;
+            pl[j] = (_Float16)(x - (float)a);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) { // A: V^T row d = 16mt + col, key slots 32s + 8q .. +7
+            const f16x8 vh = *reinterpret_cast<const f16x8*>(Vh + (16 * mt + col) * kAttnVtRow + 32 * s + 8 * q);
+            const f16x8 vl = *reinterpret_cast<const f16x8*>(Vl + (16 * mt + col) * kAttnVtRow + 32 * s + 8 * q);
+            o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[mt], 0, 0, 0);
+            o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[mt], 0, 0, 0);
+            o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[mt], 0, 0, 0);
+        }
+    }
+    const float inv = 1.0f / l;
+    const __amdgpu_buffer_rsrc_t ors = make_rsrc(out + (int64_t)b * T * kTencD, T * kTencD * 4);
+    const int ooff = (tq * kTencD + h * kTencHd + 4 * q) * 4;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[0] * inv), ors, ooff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[1] * inv), ors, ooff, 64, 0);
+}
+
 // ---- per-frame chain ---------------------------------------------------------------------
 // Between two attention calls every operation of the model is per-frame.  For
 // v_mfma_f32_16x16x4_f32 the accumulator tile of one GEMM (lane = frame, register r of M-tile
@@ -197,8 +327,6 @@ __device__ __forceinline__ void chain_gemm(const f32x4* __restrict__ wl, int lan
 // The accumulator -> operand identity of the fp32 chain carries over: k-slot (g, q, j) of the
 // 32-wide k-group g holds feature 32g + 16(j>>2) + 4q + (j&3), i.e. lane (frame, q) packs its own
 // accumulator tiles 2g (j < 4) and 2g+1 (j >= 4); the host packs the weights in the same slot order.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
 __device__ __forceinline__ void chain_split(const f32x4 (&v)[8], f16x8 (&bh)[4], f16x8 (&bl)[4]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
