@@ -157,11 +157,13 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_h3(const float* __restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
     const int tq = wave * 16 + col;
+    // K, V of the head: each thread takes dims 4c .. 4c+3 of the key PAIR (2u, 2u+1) -- adjacent
+    // slots of V^T, so a dim's two keys go out as one 32-bit LDS write
+    const int vc = threadIdx.x & 7, vu = threadIdx.x >> 3;
     f32x4 k4[2], v4[2], q4[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const int i = threadIdx.x + it * 64 * NT, t = i >> 3, c = i & 7;
-        const int off = (t * 3 * kTencD + h * kTencHd + 4 * c) * 4;
+        const int off = ((2 * vu + it) * 3 * kTencD + h * kTencHd + 4 * vc) * 4;
         k4[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, kTencD * 4, 0));
         v4[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 2 * kTencD * 4, 0));
     }
@@ -176,24 +178,31 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_h3(const float* __restr
             Vl[d * kAttnVtRow + p] = (_Float16)0.f;
         }
     }
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int i = threadIdx.x + it * 64 * NT, t = i >> 3, c = i & 7;
-        // key t -> slot: k-step t>>5, then 8*((t>>2)&3) + 4*((t>>4)&1) + (t&3)
-        const int p = (t & ~31) + 8 * ((t >> 2) & 3) + 4 * ((t >> 4) & 1) + (t & 3);
+    {
         typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        f16x4 kh, kl;
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        const int t0 = 2 * vu;
+        // key t -> slot: k-step t>>5, then 8*((t>>2)&3) + 4*((t>>4)&1) + (t&3); t0 is even: t0+1 -> p+1
+        const int p = (t0 & ~31) + 8 * ((t0 >> 2) & 3) + 4 * ((t0 >> 4) & 1) + (t0 & 3);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            f16x4 kh, kl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 a = (_Float16)k4[it][e];
+                kh[e] = a;
+                kl[e] = (_Float16)(k4[it][e] - (float)a);
+            }
+            *reinterpret_cast<f16x4*>(Kh + (t0 + it) * kTencHd + 4 * vc) = kh;
+            *reinterpret_cast<f16x4*>(Kl + (t0 + it) * kTencHd + 4 * vc) = kl;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const _Float16 a = (_Float16)k4[it][e];
-            kh[e] = a;
-            kl[e] = (_Float16)(k4[it][e] - (float)a);
-            const _Float16 vv = (_Float16)v4[it][e];
-            Vh[(4 * c + e) * kAttnVtRow + p] = vv;
-            Vl[(4 * c + e) * kAttnVtRow + p] = (_Float16)(v4[it][e] - (float)vv);
+            const _Float16 a0 = (_Float16)v4[0][e], a1 = (_Float16)v4[1][e];
+            *reinterpret_cast<f16x2*>(Vh + (4 * vc + e) * kAttnVtRow + p) = f16x2{a0, a1};
+            *reinterpret_cast<f16x2*>(Vl + (4 * vc + e) * kAttnVtRow + p) =
+                f16x2{(_Float16)(v4[0][e] - (float)a0), (_Float16)(v4[1][e] - (float)a1)};
         }
-        *reinterpret_cast<f16x4*>(Kh + t * kTencHd + 4 * c) = kh;
-        *reinterpret_cast<f16x4*>(Kl + t * kTencHd + 4 * c) = kl;
     }
     f16x8 qh, ql; // B operand of S^T, pre-scaled (torch scales q, not the scores)
 #pragma unroll
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_h3(const float* __restr
     for (int kt = 0; kt < 2 * KS; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            sc[kt][r] = expf(sc[kt][r] - mx); // masked keys: exp(-inf) = 0
+            sc[kt][r] = __expf(sc[kt][r] - mx); // v_exp_f32 (1 ulp); masked keys: exp(-inf) = 0
             l += sc[kt][r];
         }
     l += __shfl_xor(l, 16, 64);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile the TransformerEnc path (tools/bench_tenc.py --quick) on the GPU box with rocprofv3.
-#   tools/profile_tenc.sh <tag>      summaries land in gpurun_out/<tag>/
+#   [TENC_ARGS=--precision=f16x3] tools/profile_tenc.sh <tag>      summaries land in gpurun_out/<tag>/
 # Pass 1: kernel trace + stats.  Further passes: SQ counters, each in its own run.
 set -u
 TAG=${1:-prof_tenc}
@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() { # name, rocprof flags...
   local name=$1; shift
-  timeout -k 10 240 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o "$name" -- python3 "$REPO/tools/bench_tenc.py" --quick > "$OUT/$name.stdout" 2> "$OUT/$name.stderr"
+  timeout -k 10 240 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o "$name" -- python3 "$REPO/tools/bench_tenc.py" --quick ${TENC_ARGS:-} > "$OUT/$name.stdout" 2> "$OUT/$name.stderr"
   echo "[$name] rc=$?"
 }
 run trace --kernel-trace --stats
