@@ -711,3 +711,9 @@ int b2h_stream_sync(void* stream) {
 }
 
 } // extern "C"
+
+#if B2H_ABLATE & 16384
+extern "C" int b2h_debug_chain_stamps(unsigned long long* out) { // development only, not in b2h.h
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(b2h::g_chain_dbg), 8 * 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
+}
+#endif

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_h3(const float* __restr
 enum { ST_SET = 0, ST_RELU = 1, ST_RESLN_GLOBAL = 2, ST_RESLN_REG = 3, ST_STORE = 4 };
 // Development only (tools/ablate_tenc.sh): timing builds of the chain kernel with parts removed
 // -- results are wrong.  256 no LayerNorm math, 1024 no blob staging, 2048 no per-stage
-// barrier, 4096 no stores, 8192 no MFMA.
+// barrier, 4096 no stores, 8192 no MFMA, 16384 phase time stamps (tools/chain_stamps.py).
 #ifndef B2H_ABLATE
 #define B2H_ABLATE 0
 #endif
@@ -381,8 +381,22 @@ __device__ __forceinline__ f32x4 chain_ld(__amdgpu_buffer_rsrc_t rs, uint32_t of
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
 }
 
+#if B2H_ABLATE & 16384 // development: time stamps of one workgroup's phases (tools/chain_stamps.py)
+__device__ unsigned long long g_chain_dbg[8 * 64];
+#define B2H_STAMP()                                                                                        \
+    do {                                                                                                   \
+        if (blockIdx.x == gridDim.x / 2 && lane == 0 && a.nstages == 6 && nstamp < 64)                     \
+            g_chain_dbg[wave * 64 + nstamp] = __builtin_amdgcn_s_memtime();                                \
+        ++nstamp;                                                                                          \
+    } while (0)
+#else
+#define B2H_STAMP() do { } while (0)
+#endif
+
 template <bool H3> // false: fp32 operands (v_mfma_f32_16x16x4_f32); true: 3 x f16 split
 __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a) {
+    int nstamp = 0;
+    (void)nstamp;
     extern __shared__ __attribute__((aligned(16))) char smem_chain[];
     f32x4* buf0 = reinterpret_cast<f32x4*>(smem_chain);
     f32x4* buf1 = buf0 + kStageBlobMax / 4;
@@ -431,7 +445,9 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
     f16x8 bh[4], bl[4]; // H3: the GEMM operand, split from `cur`
     if constexpr (H3) chain_split(cur, bh, bl);
     put_blob(buf0, wreg);
+    B2H_STAMP(); // 0: prologue done
     __syncthreads();
+    B2H_STAMP(); // 1
 
 #pragma unroll 1
     for (int s = 0; s < a.nstages; ++s) {
@@ -451,6 +467,7 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
             acc[mt] = *reinterpret_cast<const f32x4*>(prm + 16 * (mt < st.mtiles ? mt : 0) + 4 * q);
             if (addres) acc[mt] += resid[mt];
         }
+        B2H_STAMP(); // 2 + 6s: fetch issued, accumulators initialised
         // the GEMM, branch-free for the three shapes the model has
         if constexpr (H3) {
             if (st.kgroups == 4 && st.mtiles == 8) chain_gemm_h3<4, 8>(wl, lane, bh, bl, acc);
@@ -461,9 +478,11 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
             else if (st.kgroups == 2) chain_gemm<2, 8>(wl, lane, cur, acc);
             else chain_gemm<8, 3>(wl, lane, cur, acc);
         }
+        B2H_STAMP(); // 3 + 6s: GEMM issued
         // next blob into the other buffer (free since the previous barrier), before this stage's
         // stores are issued: the wait for it then covers nothing younger
         put_blob(wn, wreg);
+        B2H_STAMP(); // 4 + 6s: blob in LDS
         // epilogue
         if (addres && !(B2H_ABLATE & 256)) {
             float sum = 0.f;
@@ -503,8 +522,9 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
         if constexpr (H3) {
             if (st.type != ST_STORE) chain_split(cur, bh, bl); // ST_STORE leaves the operand as it is
         }
+        B2H_STAMP(); // 5 + 6s: epilogue (+ split) done
         // ST_STORE writes the accumulators, other types an optional copy of the stage's result;
-        // no output = an empty descriptor.  Rows are nout floats wide: whole float4 where they fit
+        // no output = an empty descriptor (skipping the block instead measured no faster).  Rows are nout floats wide: whole float4 where they fit
         // and the two-float tail of the 42-wide head (nout is 128 or 42).
         {
             const bool on = st.out != nullptr && !(B2H_ABLATE & 4096);
@@ -524,7 +544,9 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
                 }
             }
         }
+        B2H_STAMP(); // 6 + 6s: stores issued
         if (!(B2H_ABLATE & 2048)) __syncthreads();
+        B2H_STAMP(); // 7 + 6s: past the barrier
     }
 }
 
