@@ -36,8 +36,8 @@ if ROOT not in sys.path:
 BYTES_PER_FRAME = 264      # 24 fp32 in + 42 fp32 out; weights 76 KB amortised
 FLOP_PER_FRAME = 37800     # 18 900 MAC
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32_mfma": 157.3, "f32_valu": 157.3, "fp32": 157.3}
-DTYPE = {"bf16": "bf16", "f16": "f16", "f32_mfma": "f32", "f32_valu": "f32", "fp32": "f32"}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16x3": 2500.0 / 3, "f32_mfma": 157.3, "f32_valu": 157.3, "fp32": 157.3}  # f16x3: three f16 MFMAs per product
+DTYPE = {"bf16": "bf16", "f16": "f16", "f16x3": "f16x3 (f16 hi+lo operands, fp32-grade)", "f32_mfma": "f32", "f32_valu": "f32", "fp32": "f32"}
 
 
 def parse():

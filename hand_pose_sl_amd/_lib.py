@@ -14,12 +14,13 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 _vp = ctypes.c_void_p
 
 # enum b2h_kernel
-KERNEL_AUTO, KERNEL_F32_VALU, KERNEL_F32_MFMA, KERNEL_BF16_MFMA, KERNEL_F16_MFMA = range(5)
+KERNEL_AUTO, KERNEL_F32_VALU, KERNEL_F32_MFMA, KERNEL_BF16_MFMA, KERNEL_F16_MFMA, KERNEL_F16X3_MFMA = range(6)
 KERNELS = {"auto": KERNEL_AUTO, "fp32": KERNEL_AUTO, "f32": KERNEL_AUTO,
            "f32_valu": KERNEL_F32_VALU, "fp32_valu": KERNEL_F32_VALU,
            "f32_mfma": KERNEL_F32_MFMA, "fp32_mfma": KERNEL_F32_MFMA,
            "bf16": KERNEL_BF16_MFMA, "bf16_mfma": KERNEL_BF16_MFMA,
-           "f16": KERNEL_F16_MFMA, "fp16": KERNEL_F16_MFMA, "f16_mfma": KERNEL_F16_MFMA}
+           "f16": KERNEL_F16_MFMA, "fp16": KERNEL_F16_MFMA, "f16_mfma": KERNEL_F16_MFMA,
+           "f16x3": KERNEL_F16X3_MFMA, "f16x3_mfma": KERNEL_F16X3_MFMA}
 
 # b2h_forward_fused flags
 PRE_CHEST_DIFF, PRE_NORMALIZE, POST_DENORMALIZE, POST_MASK_TAIL = 1, 2, 4, 8

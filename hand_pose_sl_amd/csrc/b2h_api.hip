@@ -16,6 +16,7 @@
 #include "b2h_common.h"
 #include "kernel_mfma.h"
 #include "kernel_mfma16.h"
+#include "kernel_mfma3.h"
 #include "kernel_tenc.h"
 #include "kernel_valu.h"
 
@@ -86,11 +87,12 @@ struct b2h_model {
     // packed device weights
     DevBuf valu_w[4], valu_b[4];
     DevBuf mf32_w[4], m_bias[4];  // exact-fp32 MFMA kernel: per-layer fragments + bias fragments
+    DevBuf m3_w[4];               // f16x3 kernel: per-layer hi / lo f16 fragments (bias shared)
     DevBuf mbf16_all, mf16_all;   // persistent 16-bit kernel: [W L0..L3 | bias L0..L3], kPacked16 bytes
     int num_cus = 256;
     ValuParams vp;
-    MfmaParams mp32;
-    bool lds_attr_set[8] = {false, false, false, false, false, false, false, false};
+    MfmaParams mp32, mp3;
+    bool lds_attr_set[9] = {false, false, false, false, false, false, false, false, false};
 };
 
 namespace {
@@ -173,13 +175,29 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
                 for (int r = 0; r < 4; ++r) bf[(mt * 4 + q) * 4 + r] = hw.bias(l, chan(mt, 4 * q + r));
         std::memcpy(ab.data() + kBiasOff16[l], bf.data(), bf.size() * 4);
         std::memcpy(ah.data() + kBiasOff16[l], bf.data(), bf.size() * 4);
+        // f16x3: [mt][tap][hi|lo][lane][8] halves, w = hi + lo with hi = f16(w), lo = f16(w - hi)
+        std::vector<_Float16> w3((size_t)MT * kTaps * 2 * 64 * 8);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int k = 0; k < kTaps; ++k)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = hw.at(l, chan(mt, lane & 15), 8 * (lane >> 4) + j, k, true);
+                        const _Float16 hi = (_Float16)v;
+                        const size_t at = ((((size_t)mt * kTaps + k) * 2) * 64 + lane) * 8 + j;
+                        w3[at] = hi;
+                        w3[at + 64 * 8] = (_Float16)(v - (float)hi);
+                    }
         int rc;
         if ((rc = m->mf32_w[l].upload(wf.data(), wf.size() * 4))) return rc;
         if ((rc = m->m_bias[l].upload(bf.data(), bf.size() * 4))) return rc;
+        if ((rc = m->m3_w[l].upload(w3.data(), w3.size() * 2))) return rc;
         m->mp32.w[l] = m->mf32_w[l].p;
         m->mp32.bias[l] = (const float*)m->m_bias[l].p;
+        m->mp3.w[l] = m->m3_w[l].p;
+        m->mp3.bias[l] = (const float*)m->m_bias[l].p;
     }
     m->mp32.pos_emb = m->pos_emb;
+    m->mp3.pos_emb = m->pos_emb;
     int rc;
     if ((rc = m->mbf16_all.upload(ab.data(), ab.size()))) return rc;
     if ((rc = m->mf16_all.upload(ah.data(), ah.size()))) return rc;
@@ -196,7 +214,8 @@ bool kernel_ok(const b2h_model* m, int k) {
         case B2H_KERNEL_F32_VALU: return m->C <= kMaxWidth;
         case B2H_KERNEL_F32_MFMA:
         case B2H_KERNEL_BF16_MFMA:
-        case B2H_KERNEL_F16_MFMA: return m->C <= kMfmaWidth;
+        case B2H_KERNEL_F16_MFMA:
+        case B2H_KERNEL_F16X3_MFMA: return m->C <= kMfmaWidth;
         default: return false;
     }
 }
@@ -256,6 +275,11 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             int rc = ensure_lds(m, 1, b2h_fwd_mfma_f32, lds);
             if (rc) return rc;
             hipLaunchKernelGGL(b2h_fwd_mfma_f32, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mp32, fa);
+        } else if (k == B2H_KERNEL_F16X3_MFMA) {
+            const size_t lds = (size_t)kWavesPerBlock * 2 * kImg3; // hi + lo images = the fp32 image's bytes
+            int rc = ensure_lds(m, 8, b2h_fwd_mfma_f16x3, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(b2h_fwd_mfma_f16x3, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mp3, fa);
         } else {
             // persistent kernel: one 512-thread workgroup per CU
             // Chunk length: whole sequences (<= 208 frames) or 192-frame chunks keep the halo
@@ -679,6 +703,7 @@ const char* b2h_kernel_name(const b2h_model* m, int kernel) {
         case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma_f32";
         case B2H_KERNEL_BF16_MFMA: return "b2h_fwd_mfma16<1, false>";
         case B2H_KERNEL_F16_MFMA: return "b2h_fwd_mfma16<2, false>";
+        case B2H_KERNEL_F16X3_MFMA: return "b2h_fwd_mfma_f16x3";
         default: return "";
     }
 }

@@ -45,7 +45,9 @@ typedef enum b2h_kernel {
     B2H_KERNEL_F32_VALU = 1,  /* fp32 FMA on the vector ALU; any conv_channels <= 64   */
     B2H_KERNEL_F32_MFMA = 2,  /* exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32)      */
     B2H_KERNEL_BF16_MFMA = 3, /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
-    B2H_KERNEL_F16_MFMA = 4   /* fp16 operands, fp32 accumulate (v_mfma_f32_16x16x32_f16)  */
+    B2H_KERNEL_F16_MFMA = 4,  /* fp16 operands, fp32 accumulate (v_mfma_f32_16x16x32_f16)  */
+    B2H_KERNEL_F16X3_MFMA = 5 /* fp32-grade: every operand split into f16 hi + lo, three f16 MFMAs per
+                                 product (hi.hi + hi.lo + lo.hi), fp32 accumulate; needs |x| < 65504 */
 } b2h_kernel;
 
 /* Pre/post-processing fused around the stack (b2h_forward_fused). */

@@ -20,10 +20,10 @@ from conftest import CONV_CASES, load_golden
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"f32_valu": 2e-5, "f32_mfma": 2e-5, "bf16": 1.5e-3, "f16": 2.5e-4}
+TOL = {"f32_valu": 2e-5, "f32_mfma": 2e-5, "f16x3": 2e-5, "bf16": 1.5e-3, "f16": 2.5e-4}   # f16x3: the fp32 bar
 TOL_MODEL = {"bf16": 6e-4, "f16": 8e-5}   # vs the oracle's operand-rounding model
 ORACLE_MODE = {"bf16": "bf16", "f16": "f16"}
-ALL_PREC = ["f32_valu", "f32_mfma", "bf16", "f16"]
+ALL_PREC = ["f32_valu", "f32_mfma", "f16x3", "bf16", "f16"]
 
 
 def _model(rec, prec, dev):
