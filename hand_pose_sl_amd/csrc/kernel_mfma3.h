@@ -17,17 +17,34 @@
 // consecutive channels of its own 16-byte chunk, so the write-back is one ds_write_b128 per image.
 #pragma once
 #include "kernel_mfma.h"
+#include "kernel_mfma16.h" // relu_bits
 
 namespace b2h {
 
 constexpr int kImg3 = kRows * 64; // bytes of one image (hi or lo) of a wave
 
+#if B2H_ABLATE & 32768 // development: s_memtime stamps of one wave's phases (tools/conv3_stamps.py)
+__device__ unsigned long long g_conv3_dbg[4 * 16];
+#define B2H_STAMP3(cx, k)                                                                                   \
+    do {                                                                                                    \
+        if (blockIdx.x == gridDim.x / 2 && (cx).lane == 0) g_conv3_dbg[(threadIdx.x >> 6) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define B2H_STAMP3(cx, k) do { } while (0)
+#endif
+
+// hi = f16(v) packed two per instruction, residual v - hi as one mixed-precision FMA per value
+// (v_fma_mix_f32 reads the f16 half directly), lo = f16(residual) packed: 16 VALU for 8 values
 __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const _Float16 a = (_Float16)v[j];
-        hi[j] = a;
-        lo[j] = (_Float16)(v[j] - (float)a);
+    for (int i = 0; i < 4; ++i) {
+        const f16x2 h = f16x2{(_Float16)v[2 * i], (_Float16)v[2 * i + 1]};
+        const float r0 = __builtin_fmaf((float)h[0], -1.0f, v[2 * i]);
+        const float r1 = __builtin_fmaf((float)h[1], -1.0f, v[2 * i + 1]);
+        const f16x2 l = f16x2{(_Float16)r0, (_Float16)r1};
+        hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
+        lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
     }
 }
 
@@ -55,8 +72,16 @@ __device__ __forceinline__ void layer3(const ChunkCtx& cx, const MfmaParams& mp)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) bias[mt] = bp[mt * 4 + cx.q];
     }
+    B2H_STAMP3(cx, 2 + 2 * L); // weight fragments requested
     const int pin = 8 - 2 * L - cx.s;
     const int pout = pin - 2;
+    // Tiles advance by 16 rows and the image's chunk swizzle has period 8, so the swizzled byte
+    // offsets of this lane's five tap rows (and of its write-back row) are those of tile 0 plus
+    // m * 1024: computed once per layer, one add per tile.
+    int roff[kTaps];
+#pragma unroll
+    for (int s = 0; s < kTaps; ++s) roff[s] = lds_off<64>(lo + cx.tcol + s - kPad + pin, cx.q);
+    int woff = lds_off<64>(lo + cx.tcol + pout, cx.q);
 
 #pragma unroll 1
     for (int m = 0; m < ntiles; ++m) {
@@ -66,9 +91,9 @@ __device__ __forceinline__ void layer3(const ChunkCtx& cx, const MfmaParams& mp)
         for (int mt = 0; mt < MT; ++mt) acc[mt] = bias[mt];
 #pragma unroll
         for (int s = 0; s < kTaps; ++s) {
-            const int off = lds_off<64>(tau + cx.tcol + s - kPad + pin, cx.q);
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(img_h + off);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(img_l + off);
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(img_h + roff[s]);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(img_l + roff[s]);
+            roff[s] += 16 * 64;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[mt][s], bh, acc[mt], 0, 0, 0);
 #pragma unroll
@@ -78,17 +103,21 @@ __device__ __forceinline__ void layer3(const ChunkCtx& cx, const MfmaParams& mp)
         }
         const int t = tau + cx.tcol;
         if constexpr (L < 3) {
-            const bool inside = t < cx.T;
             float v[8]; // channels 8q + 4mt + r = slot j = 4mt + r of this lane's chunk
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * mt + r] = inside ? fmaxf(acc[mt][r], 0.f) : 0.f;
+                for (int r = 0; r < 4; ++r) v[4 * mt + r] = relu_bits(acc[mt][r]);
+            if (tau + 16 > cx.T) { // only the tile that crosses the sequence end: frames >= T are padding
+                const bool inside = t < cx.T;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.f;
+            }
             f16x8 oh, ol;
             split8(v, oh, ol);
-            const int off = lds_off<64>(t + pout, cx.q);
-            *reinterpret_cast<f16x8*>(img_h + off) = oh;
-            *reinterpret_cast<f16x8*>(img_l + off) = ol;
+            *reinterpret_cast<f16x8*>(img_h + woff) = oh;
+            *reinterpret_cast<f16x8*>(img_l + woff) = ol;
+            woff += 16 * 64;
         } else {
             if (t < cx.e) {
                 float* yr = cx.y + (int64_t)t * kOutCh + 4 * cx.q;
@@ -108,6 +137,7 @@ __device__ __forceinline__ void layer3(const ChunkCtx& cx, const MfmaParams& mp)
             }
         }
     }
+    B2H_STAMP3(cx, 3 + 2 * L); // tiles done
     if constexpr (L < 3) {
         if (hi == cx.T) { // rows T, T+1 of the next layer's input: zero unless a tile covered them
             const int covered = lo + 16 * ntiles;
@@ -198,7 +228,8 @@ __device__ __forceinline__ void stage_input3(const ChunkCtx& cx, const float* __
 }
 
 // One wave per (sequence, chunk); no workgroup barrier anywhere.
-__global__ __launch_bounds__(64 * kWavesPerBlock) void b2h_fwd_mfma_f16x3(
+// (two 4-wave workgroups per CU by LDS: 2 waves per SIMD, so each may use 256 VGPRs)
+__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma_f16x3(
     const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem_mfma3[];
@@ -220,7 +251,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void b2h_fwd_mfma_f16x3(
     cx.fa = fa;
     cx.nvalid = T;
     if ((fa.flags & kPostMask) && fa.n_frames) cx.nvalid = fa.n_frames[cx.seq];
+    B2H_STAMP3(cx, 0);
     stage_input3(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
+    B2H_STAMP3(cx, 1); // input staged
     layer3<0>(cx, mp); layer3<1>(cx, mp); layer3<2>(cx, mp); layer3<3>(cx, mp);
 }
 
