@@ -125,10 +125,24 @@ def main():
     dev_index = local_rank % ndev          # one rank per GPU on a real node; wraps only in 1-GPU rehearsals
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
+        # The collectives here are control traffic only (barrier + max of the elapsed time): the
+        # data path is sequence-sharded with no exchange.  RCCL by default; if it cannot initialise
+        # on this node the run falls back to gloo (host tensors) rather than losing the bench line.
+        backend = args.backend
+        if backend == "nccl":
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as exc:  # noqa: BLE001 -- any RCCL failure
+                sys.stderr.write(f"[bench rank {rank}] RCCL unavailable ({type(exc).__name__}: {exc}); using gloo\n")
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+        if backend == "gloo":
             dist.init_process_group("gloo")
 
     S, T = args.seqs, args.frames
@@ -165,7 +179,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -182,6 +196,8 @@ def main():
                    "seqs_per_gpu": S, "frames_per_seq": T, "kernel": model.kernel_name(),
                    "parallelism": f"seq-shard x{world}"},
     }
+    if backend is not None:
+        out["config"]["control_backend"] = backend  # barrier + max(elapsed) only
 
     if rank == 0:
         # roofline of the dominant (only) kernel: HIP events on the launch stream
