@@ -92,6 +92,7 @@ struct b2h_model {
     int num_cus = 256;
     ValuParams vp;
     MfmaParams mp32, mp3;
+    float w_absmax = 0.f;         // largest |weight| or |bias| (NaN counts as inf): F16X3 needs < 65504
     bool lds_attr_set[9] = {false, false, false, false, false, false, false, false, false};
 };
 
@@ -114,7 +115,20 @@ struct HostWeights {
     float bias(int l, int o) const { return o < m->cout[l] ? b[l][o] : 0.f; }
 };
 
+constexpr float kF16Max = 65504.f;
+
+// largest magnitude of a set of fp32 values; a NaN makes it +inf
+float absmax_of(const std::vector<float>& v, float acc) {
+    for (float x : v) {
+        const float a = std::fabs(x);
+        if (!(a <= acc)) acc = std::isnan(a) ? INFINITY : a;
+    }
+    return acc;
+}
+
 int pack_all(b2h_model* m, const HostWeights& hw) {
+    m->w_absmax = 0.f;
+    for (int l = 0; l < 4; ++l) m->w_absmax = absmax_of(hw.b[l], absmax_of(hw.w[l], m->w_absmax));
     // ---- VALU layout: w[k][i][opad], reference channel order
     for (int l = 0; l < 4; ++l) {
         const int opad = round_up(m->cout[l], 8), cin = m->cin[l];
@@ -214,8 +228,8 @@ bool kernel_ok(const b2h_model* m, int k) {
         case B2H_KERNEL_F32_VALU: return m->C <= kMaxWidth;
         case B2H_KERNEL_F32_MFMA:
         case B2H_KERNEL_BF16_MFMA:
-        case B2H_KERNEL_F16_MFMA:
-        case B2H_KERNEL_F16X3_MFMA: return m->C <= kMfmaWidth;
+        case B2H_KERNEL_F16_MFMA: return m->C <= kMfmaWidth;
+        case B2H_KERNEL_F16X3_MFMA: return m->C <= kMfmaWidth && (!m->has_weights || m->w_absmax < kF16Max);
         default: return false;
     }
 }
@@ -252,8 +266,12 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
     if ((fa.flags & kPostMask) && !fa.n_frames)
         return fail(B2H_ERR_INVALID, "B2H_POST_MASK_TAIL needs n_frames");
     const int k = resolve_kernel(m, kernel);
-    if (!kernel_ok(m, k))
+    if (!kernel_ok(m, k)) {
+        if (k == B2H_KERNEL_F16X3_MFMA && m->C <= kMfmaWidth)
+            return fail(B2H_ERR_UNSUPPORTED, "F16X3 kernel: a weight or bias is outside the f16 range (|w| >= 65504 or "
+                                             "not finite); use the exact fp32 kernel");
         return fail(B2H_ERR_UNSUPPORTED, "kernel variant does not support conv_channels=" + std::to_string(m->C));
+    }
 
     if (k == B2H_KERNEL_F32_VALU) {
         const int tiles = (int)((T + kValuTile - 1) / kValuTile);
@@ -333,6 +351,7 @@ struct b2h_tenc {
     bool has_weights = false;
     bool lds_attr = false;
     int kernel = B2H_TENC_F32;
+    float w_absmax = 0.f; // largest |parameter| (NaN counts as inf): B2H_TENC_F16X3 needs < 65504
     DevBuf pe;
     TencBlob in_proj, out_proj;
     struct Layer {
@@ -471,6 +490,8 @@ int b2h_tenc_load_weights(b2h_tenc* m, const float* const* tensors, int count, i
         else std::memcpy(h[i].data(), tensors[i], sizes[i] * 4);
     }
     HIP_TRY(hipDeviceSynchronize());
+    m->w_absmax = 0.f;
+    for (int i = 1; i < count; ++i) m->w_absmax = absmax_of(h[i], m->w_absmax); // h[0] is the pe table (|pe| <= 1)
     int rc;
     if ((rc = m->pe.upload(h[0].data(), h[0].size() * 4))) return rc;
     if ((rc = pack_blob(m->in_proj, h[1].data(), h[2].data(), 0, D, kInCh, nullptr, nullptr))) return rc;
@@ -507,6 +528,9 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
     const int64_t n = B * T;
     if (B * kTencHeads > 0x7fffffff || n > ((int64_t)1 << 40)) return fail(B2H_ERR_SHAPE, "batch too large");
     if (!x || !y || !workspace) return fail(B2H_ERR_INVALID, "NULL pointer");
+    if (m->kernel == B2H_TENC_F16X3 && !(m->w_absmax < kF16Max))
+        return fail(B2H_ERR_UNSUPPORTED, "B2H_TENC_F16X3: a parameter is outside the f16 range (|w| >= 65504 or not "
+                                         "finite); use B2H_TENC_F32");
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
         return fail(B2H_ERR_INVALID, "x and workspace must be 16-byte aligned");
     if (workspace_bytes < b2h_tenc_workspace_bytes(m, B, T)) return fail(B2H_ERR_INVALID, "workspace too small");

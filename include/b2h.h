@@ -47,7 +47,9 @@ typedef enum b2h_kernel {
     B2H_KERNEL_BF16_MFMA = 3, /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
     B2H_KERNEL_F16_MFMA = 4,  /* fp16 operands, fp32 accumulate (v_mfma_f32_16x16x32_f16)  */
     B2H_KERNEL_F16X3_MFMA = 5 /* fp32-grade: every operand split into f16 hi + lo, three f16 MFMAs per
-                                 product (hi.hi + hi.lo + lo.hi), fp32 accumulate; needs |x| < 65504 */
+                                 product (hi.hi + hi.lo + lo.hi), fp32 accumulate; needs |x| < 65504:
+                                 a model with a weight outside that range is refused
+                                 (B2H_ERR_UNSUPPORTED), an activation beyond it becomes inf / NaN */
 } b2h_kernel;
 
 /* Pre/post-processing fused around the stack (b2h_forward_fused). */
@@ -134,7 +136,8 @@ typedef struct b2h_tenc b2h_tenc;
  *   B2H_TENC_F16X3 every operand split into f16 hi + lo, three v_mfma_f32_16x16x32_f16 per product
  *                  (hi.hi + hi.lo + lo.hi, fp32 accumulate): fp32-grade error (22 significant
  *                  bits per operand) at 3/16 of the matrix cycles, valid while every activation
- *                  and weight is below 65504 in magnitude (f16 range). */
+ *                  and weight is below 65504 in magnitude (f16 range): b2h_tenc_forward returns
+ *                  B2H_ERR_UNSUPPORTED for a model with a parameter outside it. */
 typedef enum b2h_tenc_kernel { B2H_TENC_F32 = 0, B2H_TENC_F16X3 = 1 } b2h_tenc_kernel;
 int b2h_tenc_create(int ninp, int nhead, int nhid, int nout, int nlayers, int max_len, b2h_tenc** out);
 int b2h_tenc_destroy(b2h_tenc* m);

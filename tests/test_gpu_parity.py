@@ -292,3 +292,25 @@ def test_host_pipeline_equals_direct(n, chunk, cuda_device):
     y50 = pipe.run(x[:, :50].contiguous())                  # buffers follow a new T
     with torch.no_grad():
         assert torch.equal(y50, m(x[:, :50].contiguous().to(cuda_device)).cpu())
+
+
+def test_f16x3_refuses_weights_outside_f16_range(cuda_device):
+    """The split kernel represents every operand as f16 hi + lo: a weight of magnitude >= 65504
+    (or a non-finite one) cannot be represented, so the kernel must refuse the model loudly while
+    the exact fp32 kernels keep working."""
+    rec = load_golden("cfg1_b1_t200")
+    x = torch.from_numpy(rec["x"]).to(cuda_device)
+    for bad in (1.0e5, float("inf")):
+        state = {k: torch.from_numpy(v.copy()) for k, v in rec["state"].items()}
+        state["conv2.weight"][3, 2, 1] = bad
+        m = hps.ConvModel(rec["C"], "ReLU", rec["pos_emb"], precision="f16x3")
+        m.load_state_dict(state)
+        m = m.to(cuda_device).eval()
+        with torch.no_grad(), pytest.raises(RuntimeError, match="f16 range"):
+            m(x)
+        with torch.no_grad():
+            assert m.forward_into(x, torch.empty((rec["B"], rec["T"], 21, 2), device=cuda_device),
+                                  precision="f32_mfma") is not None
+    m = _model(rec, "f16x3", cuda_device)              # in range: runs
+    with torch.no_grad():
+        assert np.abs(m(x).cpu().numpy() - rec["y"]).max() <= TOL["f16x3"]

@@ -101,3 +101,19 @@ def test_hip_batch_independence_lengths_and_errors(precision, cuda_device):
         bad = hps.TransformerEnc(24, 4, 64, 42, 2).to(cuda_device).eval()
         with torch.no_grad():
             bad(torch.zeros((1, 5, 12, 2)))
+
+
+@pytest.mark.gpu
+def test_f16x3_refuses_parameters_outside_f16_range(cuda_device):
+    state, cases = _load()
+    x, y = cases["b3_t37"]
+    bad = {k: torch.from_numpy(v.copy()) for k, v in state.items()}
+    bad["transformer_encoder.layers.1.linear1.weight"][5, 7] = 7.0e4
+    m = hps.TransformerEnc(24, 4, 128, 42, 4, precision="f16x3")
+    m.load_state_dict(bad)
+    m = m.to(cuda_device).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="f16 range"):
+        m(torch.from_numpy(x))
+    m.precision = "fp32"                                # the exact kernel takes the same weights
+    with torch.no_grad():
+        assert torch.isfinite(m(torch.from_numpy(x))).all()
