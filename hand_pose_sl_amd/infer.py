@@ -50,7 +50,7 @@ def predict_utterances(model, utterances, max_frames=200, dif_encoding=False, no
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--data", required=True, help="folder with one utterance's frame JSONs, or with one sub-folder per utterance")
+    ap.add_argument("--data", required=True, help="folder with one utterance's frame JSONs, a folder with one sub-folder per utterance, or one merged utterance file")
     ap.add_argument("--model-checkpoint", required=True)
     ap.add_argument("--output-folder", required=True)
     ap.add_argument("--model", default="Conv", choices=["Conv", "TransformerEnc"])
@@ -64,10 +64,14 @@ def main(argv=None):
 
     if os.path.isdir(args.output_folder):
         raise Exception("Experiment name " + args.output_folder + " already exists.")  # infer_utterance.py:55-56
-    subs = sorted(d for d in glob.glob(os.path.join(args.data, "*")) if os.path.isdir(d))
-    folders = subs if subs else [args.data]
-    utts = [sorted(glob.glob(os.path.join(f, "*.json"))) for f in folders]
-    utts = [(f, u) for f, u in zip(folders, utts) if u]
+    merged = os.path.isfile(args.data)   # one merged utterance file (How2Sign/util_scripts/merge_utt_jsons.py)
+    if merged:
+        utts = [(args.data, openpose.load_merged_utterance(args.data))]
+    else:
+        subs = sorted(d for d in glob.glob(os.path.join(args.data, "*")) if os.path.isdir(d))
+        folders = subs if subs else [args.data]
+        utts = [sorted(glob.glob(os.path.join(f, "*.json"))) for f in folders]
+        utts = [(f, u) for f, u in zip(folders, utts) if u]
     if not utts:
         raise SystemExit("no *.json frames under " + args.data)
 
@@ -81,6 +85,9 @@ def main(argv=None):
                                         args.normalize)
     os.mkdir(args.output_folder)
     for (folder, frames), p, n in zip(utts, pred, n_frames):
+        if merged:
+            openpose.write_merged_predictions(frames[:n], p, os.path.join(args.output_folder, os.path.basename(folder)))
+            continue
         out = args.output_folder if len(utts) == 1 else os.path.join(args.output_folder, os.path.basename(folder))
         openpose.write_predictions(frames[:n], p, out)
     print(f"wrote {sum(n_frames)} frames of {len(utts)} utterance(s) to {args.output_folder}")

@@ -205,6 +205,66 @@ def tenc_cases(hpm):
     print("tenc params", sum(v.numel() for v in model.parameters()))
 
 
+def wire_formats_case(tpd, tt, name, seed):
+    """The other two wire formats of SURVEY 8f N2, from the reference's own functions:
+    merged JSON (frames as {"json_path", "json_data"} entries: How2Sign/util_scripts/build_dataset.py:66-72,
+    consumed by select_jsons + FastTextPoseDataset.load_jsons, text_pose_dataset.py:52-68,478-505) and the HDF5
+    row (n_frames, 150) = [x*50 | y*50 | c*50], joints 8 body | 21 left | 21 right
+    (TextPoseH5Dataset.array2item / pad / clip, text_pose_dataset.py:587-632; writer-side
+    order_and_reshape_toh5, steps/traintest.py:302-317)."""
+    import json
+    import types
+    rng = np.random.default_rng(seed)
+
+    def flat(n):
+        kp = np.concatenate([rng.uniform(0, 1280, (n, 1)), rng.uniform(0, 720, (n, 1)),
+                             rng.uniform(0, 1, (n, 1))], axis=1)
+        return [float(round(v, 3)) for v in kp.reshape(-1)]
+
+    frames = [{"version": 1.3, "people": [{"person_id": [-1], "pose_keypoints_2d": flat(25),
+                                           "face_keypoints_2d": [], "hand_left_keypoints_2d": flat(21),
+                                           "hand_right_keypoints_2d": flat(21)}]} for _ in range(9)]
+    merged = [{"json_path": f"/data/utt_0/frame_{i:012d}_keypoints.json", "json_data": fr} for i, fr in enumerate(frames)]
+    rec = {"merged_json": np.array(json.dumps(merged))}
+    for n, sel in ((20, None), (9, "first"), (5, "first")):
+        chosen, start = tpd.select_jsons(merged, n, selection_type=sel)
+        item = tpd.FastTextPoseDataset.load_jsons(None, chosen)   # the variant that reads "json_data" entries (:478-505)
+        tag = f"sel{n}"
+        rec[tag + "_start"] = np.array(start)
+        rec[tag + "_paths"] = np.array(json.dumps(item["json_paths"]))
+        for k in ("body_kp", "body_conf", "right_hand_kp", "right_hand_conf", "left_hand_kp", "left_hand_conf"):
+            rec[tag + "_" + k] = np.asarray(item[k], dtype=np.float64)
+    # HDF5 row
+    row = rng.uniform(0, 1280, (7, 150)).astype(np.float32)
+    rec["h5_row"] = row
+    for mf in (12, 5):
+        fake = types.SimpleNamespace(max_frames=mf)
+        item = tpd.TextPoseH5Dataset.array2item(fake, row.copy())
+        item = tpd.TextPoseH5Dataset.pad(fake, item)
+        item = tpd.TextPoseH5Dataset.clip(fake, item)
+        for k, v in item.items():
+            rec[f"h5_m{mf}_{k}"] = np.asarray(v)
+    hand = torch.from_numpy(rng.uniform(0, 1280, (6, 21, 2)).astype(np.float32))
+    rec["h5w_in"] = hand.numpy()
+    rec["h5w_out"] = np.asarray(tt.order_and_reshape_toh5(hand))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: merged {len(merged)} frames, h5 row {row.shape}, h5 writer {rec['h5w_out'].shape}")
+
+
+def _load_traintest(utils):
+    """steps/traintest.py imports its siblings relatively (`from .utils import ...`): give it an
+    in-memory parent package whose `utils` is the module already loaded from steps/utils.py."""
+    pkg = types.ModuleType("ref_steps")
+    pkg.__path__ = [os.path.join(REF, "steps")]
+    sys.modules["ref_steps"] = pkg
+    sys.modules["ref_steps.utils"] = utils
+    spec = importlib.util.spec_from_file_location("ref_steps.traintest", os.path.join(REF, "steps", "traintest.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_steps.traintest"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def _stub_io_deps():
     """text_pose_dataset.py imports h5py at module top (absent here, unused by PoseDataset)."""
     if "h5py" not in sys.modules:
@@ -242,6 +302,8 @@ def main():
     tpd = _load(os.path.join(REF, "dataloaders", "text_pose_dataset.py"), "ref_text_pose_dataset")
     openpose_case(tpd, utils, hpm, "openpose_short_n7_m12", 7, 12, 21)
     openpose_case(tpd, utils, hpm, "openpose_long_n30_m20", 30, 20, 22)
+    # merged JSON + HDF5 row
+    wire_formats_case(tpd, _load_traintest(utils), "wire_formats", 23)
 
 
 if __name__ == "__main__":

@@ -127,3 +127,79 @@ def test_cli_with_transformer_enc(tmp_path, cuda_device):
     for i, f in enumerate(files):
         got = np.array(json.load(open(out / f))["people"][0]["hand_right_keypoints_2d"]).reshape(21, 3)
         assert np.abs(got[:, :2] - ref[i]).max() <= 2e-5 * 1280 and (got[:, 2] == 1.0).all()
+
+
+# ---- merged JSON and HDF5 row (vectors from the reference's FastTextPoseDataset.load_jsons,
+# select_jsons, TextPoseH5Dataset.array2item/pad/clip and order_and_reshape_toh5) -------------
+KP_KEYS = ("body_kp", "body_conf", "right_hand_kp", "right_hand_conf", "left_hand_kp", "left_hand_conf")
+
+
+def test_merged_json_entries_equal_reference():
+    rec = np.load(os.path.join(os.path.dirname(__file__), "golden", "wire_formats.npz"))
+    merged = json.loads(str(rec["merged_json"]))
+    for n, sel in ((20, None), (9, "first"), (5, "first")):
+        chosen, start = openpose.select_frames(merged, n, sel)
+        tag = f"sel{n}"
+        assert start == int(rec[tag + "_start"]) and len(chosen) == min(n, len(merged))
+        item = openpose.load_utterance(chosen, len(chosen))
+        assert item["json_paths"] == json.loads(str(rec[tag + "_paths"]))
+        for k in KP_KEYS:
+            assert np.array_equal(item[k], rec[tag + "_" + k].astype(np.float32)), (tag, k)
+    with pytest.raises(ValueError, match="selection_type"):
+        openpose.select_frames(merged, 5, None)            # the reference returns None here and crashes later
+
+    class FixedRng:
+        def randint(self, a, b):
+            assert (a, b) == (0, len(merged) - 4)
+            return 3
+    crop, start = openpose.select_frames(merged, 4, "randomcrop", rng=FixedRng())
+    assert start == 3 and crop == merged[3:7]
+
+
+def test_merged_utterance_file_round_trip(tmp_path):
+    rec = np.load(os.path.join(os.path.dirname(__file__), "golden", "wire_formats.npz"))
+    merged = json.loads(str(rec["merged_json"]))
+    path = tmp_path / "utt_0.json"                          # merge_utt_jsons.py layout
+    path.write_text(json.dumps([{"id": f"frame_{i}", "data": e["json_data"]} for i, e in enumerate(merged)]))
+    entries = openpose.load_merged_utterance(str(path))
+    a = openpose.load_utterance(entries, 12)
+    b = openpose.load_utterance([e["json_data"] for e in merged], 12)
+    for k in KP_KEYS:
+        assert np.array_equal(a[k], b[k])
+    assert a["n_frames"] == 9 and a["json_paths"] == [None] * 9
+    pred = np.arange(9 * 21 * 2, dtype=np.float32).reshape(9, 21, 2)
+    out = openpose.write_merged_predictions(entries, pred, str(tmp_path / "out" / "utt_0.json"))
+    back = openpose.load_merged_utterance(out)
+    assert [e["id"] for e in back] == [f"frame_{i}" for i in range(9)]
+    assert back[4]["data"]["people"][0]["hand_right_keypoints_2d"] == openpose.array2open_pose(pred[4])
+    assert back[4]["data"]["people"][0]["hand_left_keypoints_2d"] == merged[4]["json_data"]["people"][0]["hand_left_keypoints_2d"]
+    assert entries[4]["data"]["people"][0]["hand_right_keypoints_2d"] == merged[4]["json_data"]["people"][0]["hand_right_keypoints_2d"]
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps({"people": []}))
+    with pytest.raises(ValueError, match="merged utterance"):
+        openpose.load_merged_utterance(str(bad))
+
+
+def test_h5_row_codec_equals_reference():
+    rec = np.load(os.path.join(os.path.dirname(__file__), "golden", "wire_formats.npz"))
+    row = rec["h5_row"]
+    for mf in (12, 5):
+        item = openpose.h5_row_to_item(row, mf)
+        assert item["n_frames"] == min(7, mf)
+        for k in KP_KEYS:
+            assert np.array_equal(item[k], rec[f"h5_m{mf}_{k}"]), (mf, k)
+        if mf > 7:                                           # zero padding, unlike the JSON path
+            assert not item["body_kp"][7:].any() and not item["right_hand_conf"][7:].any()
+    raw = openpose.h5_row_to_item(row)
+    assert raw["body_kp"].shape == (7, 8, 2) and raw["left_hand_kp"].shape == (7, 21, 2) and raw["n_frames"] == 7
+    back = openpose.item_to_h5_row(raw["body_kp"], raw["left_hand_kp"], raw["right_hand_kp"],
+                                   raw["body_conf"], raw["left_hand_conf"], raw["right_hand_conf"])
+    assert back.dtype == np.float32 and np.array_equal(back, row)
+    assert np.array_equal(openpose.order_and_reshape_toh5(rec["h5w_in"]), rec["h5w_out"])
+    with pytest.raises(ValueError):
+        openpose.h5_row_to_item(np.zeros((3, 149), np.float32))
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="h5py"):
+            openpose.read_h5_utterance("nope.h5", "utt")
