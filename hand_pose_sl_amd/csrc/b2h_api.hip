@@ -63,6 +63,23 @@ uint16_t f32_to_f16(float f) { // round-to-nearest-even, IEEE binary16
     return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
 }
 
+// hipEvent_t that is destroyed on every exit path
+struct Event {
+    hipEvent_t e = nullptr;
+    ~Event() { if (e) (void)hipEventDestroy(e); }
+};
+
+// The library binds a model to the device current at creation; a launch from another current
+// device would run a kernel there that dereferences this device's weights.
+int check_device(int model_device) {
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != model_device)
+        return fail(B2H_ERR_INVALID, "model is bound to HIP device " + std::to_string(model_device) +
+                                        ", the current device is " + std::to_string(cur));
+    return B2H_OK;
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -254,6 +271,7 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
                                    "HandPoseModels.py:23,78-84)");
     if (B == 0) return B2H_OK;
     if (!x || !y) return fail(B2H_ERR_INVALID, "x / y is NULL");
+    if (int rc = check_device(m->device)) return rc;
     // 16-B vector loads of x rows (96 B each) and 8-B granular stores of y rows (168 B each)
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
         return fail(B2H_ERR_INVALID, "x and y must be 16-byte aligned (hipMalloc / torch allocations are)");
@@ -528,6 +546,7 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
     const int64_t n = B * T;
     if (B * kTencHeads > 0x7fffffff || n > ((int64_t)1 << 40)) return fail(B2H_ERR_SHAPE, "batch too large");
     if (!x || !y || !workspace) return fail(B2H_ERR_INVALID, "NULL pointer");
+    if (int rc = check_device(m->device)) return rc;
     if (m->kernel == B2H_TENC_F16X3 && !(m->w_absmax < kF16Max))
         return fail(B2H_ERR_UNSUPPORTED, "B2H_TENC_F16X3: a parameter is outside the f16 range (|w| >= 65504 or not "
                                          "finite); use B2H_TENC_F32");
@@ -736,19 +755,17 @@ int b2h_time_forward(b2h_model* m, const float* x, float* y, int64_t B, int64_t 
                      void* stream, float* avg_ms) {
     if (iters < 1 || !avg_ms) return fail(B2H_ERR_INVALID, "iters < 1 or avg_ms NULL");
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    Event e0, e1;
+    HIP_TRY(hipEventCreate(&e0.e));
+    HIP_TRY(hipEventCreate(&e1.e));
     FusedArgs fa{0, 1.0f, nullptr};
     int rc = B2H_OK;
-    HIP_TRY(hipEventRecord(e0, st));
+    HIP_TRY(hipEventRecord(e0.e, st));
     for (int i = 0; i < iters && rc == B2H_OK; ++i) rc = launch(m, x, y, B, T, kernel, fa, st);
-    HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventRecord(e1.e, st));
+    HIP_TRY(hipEventSynchronize(e1.e));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIP_TRY(hipEventElapsedTime(&ms, e0.e, e1.e));
     if (rc) return rc;
     *avg_ms = ms / iters;
     return B2H_OK;
