@@ -16,7 +16,7 @@
 // Both kernels address global memory with buffer instructions over per-workgroup descriptors:
 // the hardware range check replaces lane predicates, which keeps every s_waitcnt a counted one.
 // On gfx950 fp32 MFMA and VALU work do not overlap on a SIMD (tools/mfma_bench.hip), so there is
-// no attempt to hide epilogues under MFMAs: the bound is their sum (DESIGN.md section 8, N3).
+// no attempt to hide epilogues under MFMAs: the bound is their sum (DESIGN.md section 9).
 #pragma once
 #include "b2h_common.h"
 #include "kernel_mfma.h"   // f32x4

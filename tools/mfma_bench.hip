@@ -5,7 +5,7 @@
 //  (2) do matrix and vector instructions overlap on a SIMD?  "mix": an MFMA wave and a plain
 //      v_fma_f32 wave on the same SIMD, each alone and together (fp32 and f16 MFMA); and one wave
 //      with NV v_fma_f32 after every MFMA.
-// Results of round 1 are in DESIGN.md section 8 (N3): (1) one wave is enough (145-148 TFLOP/s),
+// Results of round 1 are in DESIGN.md section 9: (1) one wave is enough (145-148 TFLOP/s),
 // (2) the times add.
 #include <hip/hip_runtime.h>
 #include <cstdio>
