@@ -59,7 +59,7 @@ def main(argv=None):
     ap.add_argument("--max-frames", type=int, default=200)
     ap.add_argument("--no-normalize", dest="normalize", action="store_false")
     ap.add_argument("--dif-encoding", action="store_true")
-    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--precision", default="fp32", help="kernel: fp32 (default), f16x3 (fp32-grade, faster); Conv also bf16 / f16")
     args = ap.parse_args(argv)
 
     if os.path.isdir(args.output_folder):
@@ -78,7 +78,9 @@ def main(argv=None):
     if args.model == "Conv":
         model = ConvModel(args.conv_channels, "ReLU", pos_emb=args.conv_pos_emb, precision=args.precision)
     else:  # infer_utterance.py:99-101
-        model = TransformerEnc(ninp=12 * 2, nhead=4, nhid=128, nout=21 * 2, nlayers=4)
+        if args.precision not in ("fp32", "f16x3"):
+            raise SystemExit("--model TransformerEnc runs with --precision fp32 or f16x3")
+        model = TransformerEnc(ninp=12 * 2, nhead=4, nhid=128, nout=21 * 2, nlayers=4, precision=args.precision)
     model.load_state_dict(torch.load(args.model_checkpoint, map_location="cpu", weights_only=True))
     model = model.to("cuda").eval()
     pred, n_frames = predict_utterances(model, [u for _, u in utts], args.max_frames, args.dif_encoding,
