@@ -30,7 +30,7 @@ def wall_time(fn, n=200, warm=20):
 
 
 torch.manual_seed(0)
-models = {p: hps.ConvModel(30, "ReLU", False, precision=p).to(dev).eval() for p in ("fp32", "bf16", "f16")}
+models = {p: hps.ConvModel(30, "ReLU", False, precision=p).to(dev).eval() for p in ("fp32", "f16x3", "bf16", "f16")}
 lat = {}
 with torch.no_grad():
     for (B, T) in ((1, 1), (1, 200), (64, 200), (256, 200), (2000, 200)):
