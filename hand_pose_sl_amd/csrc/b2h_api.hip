@@ -301,7 +301,19 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         hipLaunchKernelGGL(b2h_fwd_f32_valu, dim3((unsigned)grid), dim3(256), lds, st, x, y, (int)T, tiles,
                            m->vp, fa);
     } else {
-        const int cps = (int)((T + kChunk - 1) / kChunk);
+        // chunk length of the wave-per-chunk kernels: 112 frames (the LDS image's capacity) unless
+        // that leaves most of the chip's wave slots idle (2 workgroups x 4 waves per CU); then 64 or
+        // 32 frames, paying the +-8-frame halo recompute for parallelism.  Any chunking computes
+        // bit-identical frames.
+        int chunk_len = kChunk;
+        if (k != B2H_KERNEL_BF16_MFMA && k != B2H_KERNEL_F16_MFMA) {
+            const int64_t slots = (int64_t)m->num_cus * 2 * kWavesPerBlock;
+            for (int cand : {64, 32}) {
+                if (B * ((T + chunk_len - 1) / chunk_len) * 2 >= slots) break;
+                chunk_len = cand;
+            }
+        }
+        const int cps = (int)((T + chunk_len - 1) / chunk_len);
         const int64_t nchunks = B * cps;
         const int64_t grid = (nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
         if (grid > 0x7fffffff) return fail(B2H_ERR_SHAPE, "B*T too large for one launch");
@@ -310,12 +322,12 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_F32>::kRowBytes;
             int rc = ensure_lds(m, 1, b2h_fwd_mfma_f32, lds);
             if (rc) return rc;
-            hipLaunchKernelGGL(b2h_fwd_mfma_f32, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mp32, fa);
+            hipLaunchKernelGGL(b2h_fwd_mfma_f32, g, blk, lds, st, x, y, (int)T, cps, chunk_len, nchunks, m->mp32, fa);
         } else if (k == B2H_KERNEL_F16X3_MFMA) {
             const size_t lds = (size_t)kWavesPerBlock * 2 * kImg3; // hi + lo images = the fp32 image's bytes
             int rc = ensure_lds(m, 8, b2h_fwd_mfma_f16x3, lds);
             if (rc) return rc;
-            hipLaunchKernelGGL(b2h_fwd_mfma_f16x3, g, blk, lds, st, x, y, (int)T, cps, nchunks, m->mp3, fa);
+            hipLaunchKernelGGL(b2h_fwd_mfma_f16x3, g, blk, lds, st, x, y, (int)T, cps, chunk_len, nchunks, m->mp3, fa);
         } else {
             // persistent kernel: one 512-thread workgroup per CU
             // Chunk length: whole sequences (<= 208 frames) or 192-frame chunks keep the halo

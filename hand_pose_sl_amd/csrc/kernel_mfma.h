@@ -222,7 +222,7 @@ __device__ __forceinline__ void stage_input32(const ChunkCtx& cx, const float* _
 
 // One wave per (sequence, chunk); no workgroup barrier anywhere.
 __global__ __launch_bounds__(64 * kWavesPerBlock) void b2h_fwd_mfma_f32(
-    const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq,
+    const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq, int chunk_len,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem_mfma[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -237,8 +237,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void b2h_fwd_mfma_f32(
     cx.T = T;
     cx.seq = chunk / chunks_per_seq;
     const int c = (int)(chunk - cx.seq * chunks_per_seq);
-    cx.s = c * kChunk;
-    cx.e = min(cx.s + kChunk, T);
+    cx.s = c * chunk_len; // <= kChunk frames (the LDS image's capacity); shorter when the batch is small
+    cx.e = min(cx.s + chunk_len, T);
     cx.y = y + cx.seq * (int64_t)T * kOutCh;
     cx.fa = fa;
     cx.nvalid = T;

@@ -314,3 +314,23 @@ def test_f16x3_refuses_weights_outside_f16_range(cuda_device):
     m = _model(rec, "f16x3", cuda_device)              # in range: runs
     with torch.no_grad():
         assert np.abs(m(x).cpu().numpy() - rec["y"]).max() <= TOL["f16x3"]
+
+
+@pytest.mark.parametrize("prec", ["f32_mfma", "f16x3"])
+def test_adaptive_chunk_lengths_are_bit_identical(prec, cuda_device):
+    """The wave-per-chunk kernels cut sequences into 112-frame chunks, or 64 / 32 when the batch
+    would leave most wave slots idle (b2h_api.hip launch()): the same sequences inside batches of
+    3, 400 and 1500 (-> 32, 64, 112 frames per chunk at T = 300) must come out bit-identical, and
+    equal the oracle."""
+    rec = load_golden("cfg1_b1_t200")
+    T = 300
+    g = torch.Generator().manual_seed(17)
+    x = (torch.rand((1500, T, 12, 2), generator=g) - 0.5).to(cuda_device)
+    m = _model(rec, prec, cuda_device)
+    with torch.no_grad():
+        y_big = m(x)[:3].clone()
+        y_mid = m(x[:400].contiguous())[:3].clone()
+        y_small = m(x[:3].contiguous())
+    assert torch.equal(y_big, y_mid) and torch.equal(y_big, y_small)
+    ref = oracle.forward_from_state(x[:3].cpu().numpy(), rec["state"])
+    assert np.abs(y_small.cpu().numpy() - ref).max() <= TOL[prec]
