@@ -121,18 +121,22 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
         }
         const int t = tau + cx.tcol;
         if constexpr (L < 3) {
-            const bool inside = t < cx.T;
+            f32x4 o[2];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                f32x4 o;
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = fmaxf(acc[mt][r], 0.f);
-                    o[r] = inside ? v : 0.f;
-                }
-                // channels 8q + 4mt .. +3  ->  16-B chunk 2q + mt
-                *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(t + pout, 2 * cx.q + mt)) = o;
+                for (int r = 0; r < 4; ++r) // max(v, 0) as one v_max_i32 on the bits
+                    o[mt][r] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, (float)acc[mt][r]), 0));
+            if (tau + 16 > cx.T) { // only the tile that crosses the sequence end: frames >= T are padding
+                const bool inside = t < cx.T;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[mt][r] = inside ? o[mt][r] : 0.f;
             }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) // channels 8q + 4mt .. +3  ->  16-B chunk 2q + mt
+                *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(t + pout, 2 * cx.q + mt)) = o[mt];
         } else {
             if (t < cx.e) {
                 float* yr = cx.y + (int64_t)t * kOutCh + 4 * cx.q;
@@ -220,8 +224,9 @@ __device__ __forceinline__ void stage_input32(const ChunkCtx& cx, const float* _
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One wave per (sequence, chunk); no workgroup barrier anywhere.
-__global__ __launch_bounds__(64 * kWavesPerBlock) void b2h_fwd_mfma_f32(
+// One wave per (sequence, chunk); no workgroup barrier anywhere.  Two 4-wave workgroups per CU by
+// LDS = 2 waves per SIMD, so a wave may use 256 VGPRs (keeps the accumulators out of AGPRs).
+__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma_f32(
     const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq, int chunk_len,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem_mfma[];
