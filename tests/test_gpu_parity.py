@@ -159,7 +159,7 @@ def test_large_stream_properties(cuda_device):
     rec = load_golden("cfg1_b1_t200")
     g = torch.Generator().manual_seed(11)
     blk = (torch.rand((4096, 200, 12, 2), generator=g) - 0.5).to(cuda_device)
-    for prec, reps in (("bf16", 64), ("f32_mfma", 16)):
+    for prec, reps in (("bf16", 64), ("f32_mfma", 16), ("f16x3", 32)):
         x = blk.repeat(reps, 1, 1, 1)
         n = reps * 4096
         m = _model(rec, prec, cuda_device)
@@ -175,7 +175,7 @@ def test_large_stream_properties(cuda_device):
         del y, x
 
 
-@pytest.mark.parametrize("prec", ["bf16", "f32_mfma"])
+@pytest.mark.parametrize("prec", ["bf16", "f32_mfma", "f16x3"])
 def test_hip_graph_capture_and_replay(prec, cuda_device):
     """The launch path does no allocation or synchronisation, so a caller can capture it
     into a HIP graph (torch.cuda.CUDAGraph on ROCm) and replay it on fresh data."""
