@@ -224,6 +224,20 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
 
+    if rank == 0 and world == 1:
+        # informational: the same shard through the fp32-grade and the exact-fp32 kernels (a few
+        # launches each; not part of `value`)
+        other = {}
+        for prec, it in (("f16x3", 5), ("f32_mfma", 3)):
+            if prec == args.precision:
+                continue
+            try:
+                ms_o = model.time_forward(x, y, it, precision=prec)
+                other[prec] = {"launch_ms": ms_o, "frames_per_s": S * T / (ms_o * 1e-3), "kernel": model.kernel_name(prec)}
+            except RuntimeError as exc:
+                other[prec] = {"error": str(exc)}
+        out["other_kernels"] = other
+
     if args.gather and world >= 1:
         from hand_pose_sl_amd.stream import ShardedStream, shard_bounds
         n_seq = 2000
