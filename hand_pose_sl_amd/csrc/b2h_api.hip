@@ -556,7 +556,8 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
                                    "HandPoseModels.py:101,167)");
     if (B == 0) return B2H_OK;
     const int64_t n = B * T;
-    if (B * kTencHeads > 0x7fffffff || n > ((int64_t)1 << 40)) return fail(B2H_ERR_SHAPE, "batch too large");
+    // grid limits: attention launches B x heads workgroups, the chain n / 128
+    if (B * kTencHeads > 0x7fffffff || n / (16 * kLinWaves) >= 0x7fffffff) return fail(B2H_ERR_SHAPE, "batch too large for one launch");
     if (!x || !y || !workspace) return fail(B2H_ERR_INVALID, "NULL pointer");
     if (int rc = check_device(m->device)) return rc;
     if (m->kernel == B2H_TENC_F16X3 && !(m->w_absmax < kF16Max))
