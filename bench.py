@@ -107,6 +107,12 @@ def cpu_baseline(model, seconds):
 
 def main():
     args = parse()
+    # Rank 0 prints exactly ONE line on stdout: the JSON.  Libraries underneath (RCCL's version
+    # banner, gloo's connection notes, hipcc when the extension is rebuilt) write to fd 1 as they
+    # please, so fd 1 is pointed at stderr for the whole run and the JSON goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -261,7 +267,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(model, args.cpu_seconds)
 
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
