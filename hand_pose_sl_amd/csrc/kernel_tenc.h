@@ -1,21 +1,27 @@
-// TransformerEnc (body2hand/src/models/HandPoseModels.py:118-178) on gfx950, exact fp32
-// (SURVEY.md 8f N3).  Two kernels, both on v_mfma_f32_16x16x4_f32:
+// TransformerEnc (body2hand/src/models/HandPoseModels.py:118-178) on gfx950.
+// Two kernels per precision:
 //
-//   b2h_attn_mfma_f32   self-attention, workgroup = (sequence, head), wave = 16 query frames:
+//   b2h_attn_mfma_f32 / b2h_attn_mfma_h3
+//                       self-attention, workgroup = (sequence, head), wave = 16 query frames:
 //                       scores and P.V on the matrix cores, softmax in registers over all T keys
 //                       (the reference passes no mask, HandPoseModels.py:170).
-//   b2h_tenc_chain_f32  everything between two attention calls, which is all per-frame: a wave
+//   b2h_tenc_chain<H3>  everything between two attention calls, which is all per-frame: a wave
 //                       carries 16 frames through a chain of Linear layers in registers (the
 //                       accumulator layout IS the next GEMM's operand layout), with bias, ReLU,
 //                       residual + LayerNorm fused between them; weights double-buffered in LDS.
+//
+// B2H_TENC_F32 computes every product in fp32 (v_mfma_f32_16x16x4_f32); B2H_TENC_F16X3 (the _h3 /
+// <true> instantiations) splits every operand into f16 hi + lo and uses three
+// v_mfma_f32_16x16x32_f16 per product with fp32 accumulation: fp32-grade results at 3/16 of the
+// matrix cycles.  Softmax, LayerNorm, bias and residual arithmetic is fp32 in both.
 //
 // Per forward: 1 front chain (src + pe -> pose2hidden -> Q,K,V) and per layer 1 attention + 1
 // chain launch; only the residual stream, the attention output and Q,K,V cross HBM (2.5 KB per
 // frame of caller-provided workspace).
 //
-// Both kernels address global memory with buffer instructions over per-workgroup descriptors:
+// All kernels address global memory with buffer instructions over per-workgroup descriptors:
 // the hardware range check replaces lane predicates, which keeps every s_waitcnt a counted one.
-// On gfx950 fp32 MFMA and VALU work do not overlap on a SIMD (tools/mfma_bench.hip), so there is
+// On gfx950 MFMA and VALU work do not overlap on a SIMD (tools/mfma_bench.hip), so there is
 // no attempt to hide epilogues under MFMAs: the bound is their sum.
 #pragma once
 #include "b2h_common.h"
