@@ -312,6 +312,19 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
                         // lvalue reads element 0 in this clang)
                         __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])},
                                                               yrs, yoff, so, 0);
+                    if constexpr (FUSED) {
+                        // Store-data write-after-read hazard on gfx950 (hipcc, ROCm 7.2 pads nothing here):
+                        // the fused epilogue computes the NEXT M-tile's vector (v_pk_mul_f32) into the
+                        // registers this store is still reading; issued back to back, the store picks up
+                        // the new value for its second dword in the last lanes of each 16-lane group
+                        // (out[mt][1] = acc[mt+1][3] x mul at tcol 12..15).  It only bit when an epilogue
+                        // ran without MFMAs in between: head layer with an odd tile count, last tile full
+                        // (T mod 32 in 13..16); found by tools/stress_conv.py, pinned by
+                        // test_fused_every_length.  Four wait states between a store and what follows it.
+                        __builtin_amdgcn_sched_barrier(0); // (a memory clobber alone does not keep VALU instructions from moving above the nop)
+                        asm volatile("s_nop 3" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }

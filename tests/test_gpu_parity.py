@@ -334,3 +334,27 @@ def test_adaptive_chunk_lengths_are_bit_identical(prec, cuda_device):
     assert torch.equal(y_big, y_mid) and torch.equal(y_big, y_small)
     ref = oracle.forward_from_state(x[:3].cpu().numpy(), rec["state"])
     assert np.abs(y_small.cpu().numpy() - ref).max() <= TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ALL_PREC)
+def test_fused_every_length(prec, cuda_device):
+    """The fused instantiation against the plain kernel of the same precision at EVERY length 1..80
+    and around the chunk sizes, small and large batch (different chunkings), with numerically
+    neutral flags (x 1.0, a tail mask that masks nothing): the results must be bit-identical.
+    Regression test for a store-data write-after-read hazard in the fused 16-bit kernel that only
+    showed when the head layer had an odd number of tiles and the last tile was full
+    (T mod 32 in 13..16; tools/stress_conv.py found it)."""
+    rec = load_golden("cfg1_b1_t200")
+    m = _model(rec, prec, cuda_device)
+    g = torch.Generator().manual_seed(23)
+    lengths = list(range(1, 81)) + [95, 96, 111, 112, 113, 143, 144, 176, 191, 192, 193, 207, 208, 209, 240, 400, 432, 500]
+    for T in lengths:
+        for B in ((2, 600) if T <= 208 else (2, 40)):
+            x = (torch.rand((B, T, 12, 2), generator=g) - 0.5).to(cuda_device)
+            with torch.no_grad():
+                plain = m(x)
+                a = m.forward_fused(x, dif_encoding=False, normalize=False, denormalize=True, factor=1.0)
+                b = m.forward_fused(x, dif_encoding=False, normalize=False, denormalize=False, mask_tail=True,
+                                    n_frames=[T] * B)
+            assert torch.equal(a, plain), (prec, B, T, "x1.0")
+            assert torch.equal(b, plain), (prec, B, T, "mask nothing")

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""GPU box: randomized sweep of the ConvModel kernels against the oracle -- random width
+(1..32 on the MFMA kernels, up to 64 on the VALU one), pos_emb, batch, length, kernel and
+fused-transform flags; every case must meet the kernel's parity tolerance.
+    python tools/stress_conv.py [seconds=120] [seed=0]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hand_pose_sl_amd as hps
+import oracle
+
+TOL = {"f32_valu": 2e-5, "f32_mfma": 2e-5, "f16x3": 2e-5, "bf16": 1.5e-3, "f16": 2.5e-4}   # 16-bit: vs the rounding model, with room for tie flips under the scaled weights
+# fp32-class kernels: vs the fp32 oracle.  16-bit kernels: vs the oracle's operand-rounding model
+# (mode="bf16"/"f16": same rounding of operands, fp32 accumulation), which isolates kernel bugs from
+# the precision's own error.  Tolerances scale with the largest activation magnitude of the case.
+MODE = {"bf16": "bf16", "f16": "f16"}
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda:0")
+t_end = time.time() + budget
+n = 0
+worst = {k: 0.0 for k in TOL}
+while time.time() < t_end:
+    prec = str(rng.choice(list(TOL)))
+    pos_emb = bool(rng.random() < 0.15)
+    C = int(rng.integers(1, 65 if prec == "f32_valu" else 33))
+    T = 100 if pos_emb else int(rng.choice([rng.integers(1, 40), rng.integers(40, 260), rng.integers(260, 900)]))
+    B = int(rng.choice([1, 2, 3, rng.integers(4, 40), rng.integers(40, 700)]))
+    if B * T > 150000:
+        B = max(1, 150000 // T)
+    torch.manual_seed(int(rng.integers(1 << 30)))
+    m = hps.ConvModel(C, "ReLU", pos_emb, precision=prec)
+    with torch.no_grad():                       # livelier weights than the default init
+        for p in m.parameters():
+            p.mul_(float(rng.uniform(0.7, 1.6)))
+    m = m.to(dev).eval()
+    state = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    fused = rng.random() < 0.35
+    if fused:
+        body = (rng.random((B, T, 12, 2), dtype=np.float32) * np.array([1280.0, 720.0], np.float32))
+        nf = rng.integers(0, T + 1, B)
+        dif, norm, den, mask = (bool(rng.random() < 0.7) for _ in range(4))
+        with torch.no_grad():
+            y = m.forward_fused(torch.from_numpy(body).to(dev), n_frames=nf if mask else None, dif_encoding=dif,
+                                normalize=norm, denormalize=den, mask_tail=mask).cpu().numpy()
+        inp, _ = oracle.preprocess(body, None, dif_encoding=dif, normalize=norm)
+        ref = oracle.forward_from_state(inp, state, pos_emb=pos_emb, mode=MODE.get(prec, "fp32"))
+        scale = max(1.0, float(np.abs(ref).max()), float(np.abs(inp).max()))
+        ref = oracle.postprocess(ref, 1280.0 if den else 1.0, nf if mask else None)
+        tol = TOL[prec] * scale * (1280.0 if den else 1.0)
+    else:
+        x = (rng.random((B, T, 12, 2), dtype=np.float32) - 0.5) * float(rng.choice([1.0, 1.0, 4.0]))
+        with torch.no_grad():
+            y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+        ref = oracle.forward_from_state(x, state, pos_emb=pos_emb, mode=MODE.get(prec, "fp32"))
+        tol = TOL[prec] * max(1.0, float(np.abs(ref).max()), float(np.abs(x).max()))
+    err = float(np.abs(y - ref).max())
+    rel = err / tol
+    worst[prec] = max(worst[prec], rel)
+    n += 1
+    if not (err <= tol) or not np.isfinite(y).all():
+        print(f"FAIL case {n}: prec={prec} C={C} pos_emb={pos_emb} B={B} T={T} fused={fused} err={err:.3e} tol={tol:.3e}")
+        if fused:
+            print(f"  flags: dif={dif} norm={norm} den={den} mask={mask}  n_frames[:8]={nf[:8].tolist()}")
+        bad = np.argwhere(np.abs(y - ref) > tol)
+        print(f"  {len(bad)} elements off; first {bad[:5].tolist()}; last {bad[-3:].tolist()}")
+        b0, t0 = bad[0][0], bad[0][1]
+        print(f"  y[{b0},{t0},0]={y[b0, t0, 0]} ref={ref[b0, t0, 0]}; frames off in seq {b0}: {sorted(set(bad[bad[:, 0] == b0][:, 1].tolist()))[:40]}")
+        sys.exit(1)
+    if n % 50 == 0:
+        print(f"{n} cases ok; worst err/tol so far {{{', '.join(f'{k}: {v:.2f}' for k, v in worst.items())}}}", flush=True)
+print(f"PASS: {n} random cases in {budget:.0f} s; worst err/tol {{{', '.join(f'{k}: {v:.2f}' for k, v in worst.items())}}}")
