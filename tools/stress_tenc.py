@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""GPU box: randomized sweep of the TransformerEnc path against the numpy oracle -- random batch,
+length (1..100), layer count, weight scale and kernel (fp32 / f16x3); plus the masked-L1 metric
+and the target transform on random shapes.    python tools/stress_tenc.py [seconds=120] [seed=0]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hand_pose_sl_amd as hps
+import oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+t_end = time.time() + budget
+n, worst = 0, {"fp32": 0.0, "f16x3": 0.0, "l1": 0.0}
+models = {}
+while time.time() < t_end:
+    prec = str(rng.choice(["fp32", "f16x3"]))
+    L = int(rng.choice([1, 2, 4, 4, 4, 6]))
+    key = (prec, L, n // 25)                                  # fresh weights every 25 cases
+    if key not in models:
+        torch.manual_seed(int(rng.integers(1 << 30)))
+        m = hps.TransformerEnc(24, 4, 128, 42, L, precision=prec)
+        with torch.no_grad():
+            for name, p in m.named_parameters():
+                if "norm" not in name:
+                    p.mul_(float(rng.uniform(0.6, 1.8)))
+        models = {key: (m.to(dev).eval(), {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()})}
+    m, state = models[key]
+    T = int(rng.integers(1, 101))
+    B = int(rng.choice([1, 2, 3, rng.integers(4, 24)]))
+    x = ((rng.random((B, T, 12, 2), dtype=np.float32) - 0.5) * float(rng.choice([1.0, 1.0, 3.0])))
+    with torch.no_grad():
+        y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+    ref = oracle.transformer_forward(x, state)
+    err = float(np.abs(y - ref).max())
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+    worst[prec] = max(worst[prec], err / tol)
+    n += 1
+    if not (err <= tol) or not np.isfinite(y).all():
+        print(f"FAIL case {n}: prec={prec} L={L} B={B} T={T} err={err:.3e} tol={tol:.3e}")
+        sys.exit(1)
+    if n % 10 == 0:                                           # metric + target transform on the side
+        Bm, Tm = int(rng.integers(1, 40)), int(rng.integers(1, 300))
+        pred = rng.standard_normal((Bm, Tm, 21, 2)).astype(np.float32)
+        tgt = rng.standard_normal((Bm, Tm, 21, 2)).astype(np.float32)
+        nf = rng.integers(1, Tm + 1, Bm)
+        got = float(hps.masked_pose_l1(torch.from_numpy(pred).to(dev), torch.from_numpy(tgt).to(dev), torch.from_numpy(nf).to(dev)))
+        want = float(oracle.masked_l1(pred, tgt, nf)[0])
+        e = abs(got - want) / max(1e-6, abs(want))
+        worst["l1"] = max(worst["l1"], e / 2e-6)
+        if e > 2e-6:
+            print(f"FAIL masked_l1 B={Bm} T={Tm}: {got} vs {want}")
+            sys.exit(1)
+    if n % 100 == 0:
+        print(f"{n} cases ok; worst err/tol {{{', '.join(f'{k}: {v:.2f}' for k, v in worst.items())}}}", flush=True)
+print(f"PASS: {n} random cases in {budget:.0f} s; worst err/tol {{{', '.join(f'{k}: {v:.2f}' for k, v in worst.items())}}}")
