@@ -358,3 +358,24 @@ def test_fused_every_length(prec, cuda_device):
                                     n_frames=[T] * B)
             assert torch.equal(a, plain), (prec, B, T, "x1.0")
             assert torch.equal(b, plain), (prec, B, T, "mask nothing")
+
+
+@pytest.mark.parametrize("prec", ALL_PREC)
+def test_very_long_sequence_plain_and_fused(prec, cuda_device):
+    """T = 70 001 frames (hundreds of chunks per sequence, byte offsets past 2^23): plain forward and
+    the fused pixel pipeline with a ragged tail mask, against the oracle."""
+    rec = load_golden("cfg1_b1_t200")
+    rng = np.random.default_rng(9)
+    B, T = 2, 70001
+    x = rng.random((B, T, 12, 2), dtype=np.float32) - 0.5
+    body = (x + 0.5) * np.array([1280.0, 720.0], np.float32)
+    nf = np.array([T, 12345])
+    m = _model(rec, prec, cuda_device)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x).to(cuda_device)).cpu().numpy()
+        yf = m.forward_fused(torch.from_numpy(body).to(cuda_device), n_frames=nf, mask_tail=True).cpu().numpy()
+    assert np.abs(y - oracle.forward_from_state(x, rec["state"])).max() <= TOL[prec]
+    inp, _ = oracle.preprocess(body, None)
+    ref = oracle.postprocess(oracle.forward_from_state(inp, rec["state"]), 1280.0, nf)
+    assert np.abs(yf - ref).max() <= 2 * TOL[prec] * 1280
+    assert not yf[1, 12345:].any()
