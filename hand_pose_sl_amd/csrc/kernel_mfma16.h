@@ -305,6 +305,7 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, lane * 16, (m * 3 + mt) * 1024, 0);
                         continue;
                     }
+                    if constexpr (FUSED) __builtin_amdgcn_sched_barrier(0); // store + its wait states stay adjacent (below)
                     if (mt < 2 || q < 2)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff, so, 0);
                     else if (q == 2) // channels 40, 41
@@ -321,7 +322,8 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
                         // ran without MFMAs in between: head layer with an odd tile count, last tile full
                         // (T mod 32 in 13..16); found by tools/stress_conv.py, pinned by
                         // test_fused_every_length.  Four wait states between a store and what follows it.
-                        __builtin_amdgcn_sched_barrier(0); // (a memory clobber alone does not keep VALU instructions from moving above the nop)
+                        // (fenced on both sides -- above the store and here: a memory clobber alone keeps
+                        // neither VALU instructions nor MFMAs from moving between the store and the nop)
                         asm volatile("s_nop 3" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
                     }

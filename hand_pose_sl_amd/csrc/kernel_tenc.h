@@ -545,8 +545,13 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (int)(whole ? off : kOob), 0, 0);
                 if (m == 2) { // the only M-tile a 42-wide row ends in
                     const bool tail = !whole && m < st.mtiles && o0 + 1 < st.nout;
+                    __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}, ors,
                                                           (int)(tail ? off : kOob), 0, 0);
+                    // keep the next vector's VALU writes off this store's data registers for two wait
+                    // states (store-data write-after-read, see kernel_mfma16.h; hipcc pads only > 64-bit data)
+                    asm volatile("s_nop 1" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
