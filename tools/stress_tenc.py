@@ -34,7 +34,10 @@ while time.time() < t_end:
         y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
     ref = oracle.transformer_forward(x, state)
     err = float(np.abs(y - ref).max())
-    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+    # fp32: the tests' 2e-5 bar.  f16x3: the same bar holds on reference-scale weights (fixed tests);
+    # with weights scaled up to 1.8x per tensor here its error reached 0.95 of it in 12 485 cases, so
+    # the sweep gives it 2x headroom -- it is looking for structural errors, which are O(0.1)
+    tol = (2e-5 if prec == "fp32" else 4e-5) * max(1.0, float(np.abs(ref).max()))
     worst[prec] = max(worst[prec], err / tol)
     n += 1
     if not (err <= tol) or not np.isfinite(y).all():
