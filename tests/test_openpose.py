@@ -102,6 +102,32 @@ def test_utterance_inference_end_to_end(name, tmp_path, cuda_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_merged_file_inference_end_to_end(name, tmp_path, cuda_device):
+    """The same flow with the utterance given as ONE merged file (merge_utt_jsons.py layout), with the
+    fp32-grade f16x3 kernel: same predictions, written back as one merged file."""
+    from hand_pose_sl_amd import infer
+    rec = load_golden(name)
+    frames = _frames(rec)
+    merged = tmp_path / "utt_7.json"
+    merged.write_text(json.dumps([{"id": f"utt_7_{i:012d}_keypoints", "data": fr} for i, fr in enumerate(frames)]))
+    ckpt = tmp_path / "best_model.pth"
+    torch.save({k: torch.from_numpy(v) for k, v in rec["state"].items()}, ckpt)
+    out = tmp_path / "out"
+    infer.main(["--data", str(merged), "--model-checkpoint", str(ckpt), "--output-folder", str(out),
+                "--max-frames", str(rec["T"]), "--precision", "f16x3"])
+    assert os.listdir(out) == ["utt_7.json"]
+    back = openpose.load_merged_utterance(str(out / "utt_7.json"))
+    n = min(int(rec["n_frames"]), rec["T"])
+    assert len(back) == n and [e["id"] for e in back] == [f"utt_7_{i:012d}_keypoints" for i in range(n)]
+    expect = json.loads(str(rec["out_hands_json"]))
+    for e, hand, fr in zip(back, expect, frames):
+        got = e["data"]["people"][0]["hand_right_keypoints_2d"]
+        assert np.abs(np.array(got) - np.array(hand)).max() <= 2e-5 * 1280
+        assert e["data"]["people"][0]["pose_keypoints_2d"] == fr["people"][0]["pose_keypoints_2d"]
+
+
+@pytest.mark.gpu
 def test_cli_with_transformer_enc(tmp_path, cuda_device):
     """--model TransformerEnc (infer_utterance.py:99-101): frames in, frames out, values equal the
     oracle's transformer on the same staged, normalised input."""
