@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: randomized sweep of the TransformerEnc path against the numpy oracle -- random batch,
 length (1..100), layer count, weight scale and kernel (fp32 / f16x3); plus the masked-L1 metric
-and the target transform on random shapes.    python tools/stress_tenc.py [seconds=120] [seed=0]"""
+and the target transform (bit-exact) on random shapes.    python tools/stress_tenc.py [seconds=120] [seed=0]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -54,6 +54,15 @@ while time.time() < t_end:
         worst["l1"] = max(worst["l1"], e / 2e-6)
         if e > 2e-6:
             print(f"FAIL masked_l1 B={Bm} T={Tm}: {got} vs {want}")
+            sys.exit(1)
+        body = (rng.random((Bm, Tm, 12, 2), dtype=np.float32) * np.array([1280.0, 720.0], np.float32))
+        hand = (rng.random((Bm, Tm, 21, 2), dtype=np.float32) * np.array([1280.0, 720.0], np.float32))
+        dif, norm = bool(rng.random() < 0.7), bool(rng.random() < 0.7)
+        tt = hps.target_transform(torch.from_numpy(body).to(dev), torch.from_numpy(hand).to(dev), dif_encoding=dif,
+                                  normalize=norm).cpu().numpy()
+        _, want_t = oracle.preprocess(body, hand, dif_encoding=dif, normalize=norm)
+        if not np.array_equal(tt, want_t):
+            print(f"FAIL target_transform B={Bm} T={Tm} dif={dif} norm={norm}: max diff {np.abs(tt - want_t).max()}")
             sys.exit(1)
     if n % 100 == 0:
         print(f"{n} cases ok; worst err/tol {{{', '.join(f'{k}: {v:.2f}' for k, v in worst.items())}}}", flush=True)
