@@ -95,3 +95,25 @@ def check(rc):
     if rc == ERR_INVALID:
         raise ValueError(msg)            # e.g. activation != "ReLU", HandPoseModels.py:34-37
     raise RuntimeError(f"libb2h: {msg} (status {rc})")
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def on_device(dev):
+    """Context in which `dev` is the current HIP device: a no-op object when it already is (the
+    usual one-process-per-GPU case), torch.cuda.device(dev) otherwise.  The library checks the
+    current device on every forward (b2h.h), so the switch is for correctness, the shortcut for the
+    few microseconds two hipSetDevice calls cost on a small-batch call."""
+    import torch
+    if torch.cuda.current_device() == dev.index:
+        return _NO_SWITCH
+    return torch.cuda.device(dev)

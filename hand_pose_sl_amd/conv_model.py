@@ -114,7 +114,7 @@ class ConvModel(nn.Module):
         x = self._check_input(inp)
         B, T = x.shape[0], x.shape[1]
         y = torch.empty((B, T, 21, 2), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             st = torch.cuda.current_stream(x.device).cuda_stream
             _lib.check(lib.b2h_forward(self._handle, ctypes.c_void_p(x.data_ptr()),
                                        ctypes.c_void_p(y.data_ptr()), B, T,
@@ -132,7 +132,7 @@ class ConvModel(nn.Module):
         for t in (x, y):
             if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError("forward_into needs contiguous float32 tensors on the model's device")
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.b2h_forward(self._handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
                                        x.shape[0], x.shape[1], _lib.KERNELS[precision or self.precision],
@@ -157,7 +157,7 @@ class ConvModel(nn.Module):
             if nf.shape != (B,):
                 raise RuntimeError(f"n_frames must have shape ({B},)")
         y = torch.empty((B, T, 21, 2), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             st = torch.cuda.current_stream(x.device).cuda_stream
             _lib.check(lib.b2h_forward_fused(self._handle, ctypes.c_void_p(x.data_ptr()),
                                              ctypes.c_void_p(y.data_ptr()), B, T, flags, float(factor),
@@ -170,7 +170,7 @@ class ConvModel(nn.Module):
         the launch stream (b2h_time_forward)."""
         lib = self._ensure_handle()
         ms = ctypes.c_float()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             st = torch.cuda.current_stream(x.device).cuda_stream
             _lib.check(lib.b2h_time_forward(self._handle, ctypes.c_void_p(x.data_ptr()),
                                             ctypes.c_void_p(y.data_ptr()), x.shape[0], x.shape[1],
@@ -189,7 +189,7 @@ def target_transform(body, hand, dif_encoding=True, normalize=True, factor=1280.
     B, T = body.shape[0], body.shape[1]
     out = torch.empty_like(hand)
     flags = (1 if dif_encoding else 0) | (2 if normalize else 0)
-    with torch.cuda.device(body.device):
+    with _lib.on_device(body.device):
         st = torch.cuda.current_stream(body.device).cuda_stream
         _lib.check(lib.b2h_target_transform(ctypes.c_void_p(body.data_ptr()), ctypes.c_void_p(hand.data_ptr()),
                                             ctypes.c_void_p(out.data_ptr()), B, T, flags, float(factor),

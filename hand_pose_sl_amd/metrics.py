@@ -30,7 +30,7 @@ def masked_pose_l1(prediction, target, lengths=None, return_per_sequence=False):
     per_seq = torch.empty((B,), dtype=torch.float32, device=p.device)
     loss = torch.empty((), dtype=torch.float32, device=p.device)
     lib = _lib.load()
-    with torch.cuda.device(p.device):
+    with _lib.on_device(p.device):
         st = torch.cuda.current_stream(p.device).cuda_stream
         _lib.check(lib.b2h_masked_l1(ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(t.data_ptr()),
                                      ctypes.c_void_p(nf.data_ptr()) if nf is not None else None, B, T,

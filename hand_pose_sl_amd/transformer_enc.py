@@ -124,7 +124,7 @@ class TransformerEnc(nn.Module):
         if ws is None or ws.numel() < need or ws.device != dev:
             ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
             self.__dict__["_workspace"] = ws
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.b2h_tenc_set_kernel(self._handle, TENC_KERNELS[self.precision]))
             _lib.check(lib.b2h_tenc_forward(self._handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
