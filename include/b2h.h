@@ -73,7 +73,8 @@ int b2h_device_count(void);
  * Replaces ConvModel.__init__(conv_channels, activation, pos_emb)
  * (HandPoseModels.py:18-37).  `activation` must be "ReLU" (B2H_ERR_INVALID
  * otherwise, mirroring the ValueError at :34-37).  1 <= conv_channels <= 64.
- * The model is bound to the HIP device current at creation. */
+ * The model is bound to the HIP device current at creation; b2h_forward / b2h_forward_fused (and
+ * b2h_tenc_forward for its model) return B2H_ERR_INVALID when called while another device is current. */
 int b2h_create(int conv_channels, const char* activation, int pos_emb, b2h_model** out);
 int b2h_destroy(b2h_model* m);
 
