@@ -167,7 +167,7 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
         if (as < m->cin[0]) as = m->cin[0];
         m->vp.act_stride = as | 1;
         int wb = 0;
-        for (int l = 0; l < 4; ++l) wb = std::max(wb, kTaps * m->vp.L[l].cin * m->vp.L[l].opad);
+        for (int l = 0; l < 4; ++l) wb = std::max(wb, m->vp.L[l].cin * m->vp.L[l].opad); // one tap at a time
         m->vp.wbuf_floats = wb;
         m->vp.pos_emb = m->pos_emb;
     }

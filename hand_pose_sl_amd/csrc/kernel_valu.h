@@ -5,7 +5,7 @@
 // all four layers (HandPoseModels.py:55-58).  It loads the 80 input frames it
 // depends on (+-8 halo) straight from the native (B,T,24) layout -- the
 // reference's permute/view (:43-46) is a stride change only -- keeps both
-// activation buffers and the current layer's weights in LDS, and writes
+// activation buffers and ONE TAP of the current layer's weights in LDS, and writes
 // (B,T,42) == (B,T,21,2) contiguous.  Activations outside [0,T) are forced to
 // zero after EVERY layer, which is what per-layer `padding=2` means.
 #pragma once
@@ -64,47 +64,68 @@ __global__ __launch_bounds__(256) void b2h_fwd_f32_valu(const float* __restrict_
     int64_t nvalid = T;
     if ((fa.flags & kPostMask) && fa.n_frames) nvalid = fa.n_frames[b];
 
+    constexpr int kMaxItems = 3; // (rows, 8-channel group) items per thread: <= 76 rows x 8 groups / 256 threads
 #pragma unroll 1
     for (int l = 0; l < 4; ++l) {
         const ValuLayer L = p.L[l];
-        __syncthreads(); // previous layer done with wbuf / `in` complete
-        for (int i = tid * 4; i < kTaps * L.cin * L.opad; i += 256 * 4)
-            *reinterpret_cast<float4*>(wbuf + i) = *reinterpret_cast<const float4*>(L.w + i);
-        __syncthreads();
-
         const int ng = L.opad / 8;
         const int rlo = 2 * (l + 1), nrows = kValuRows - 4 * (l + 1);
-        for (int item = tid; item < nrows * ng; item += 256) {
-            const int r = rlo + item / ng, g = item % ng;
-            float acc[8];
+        const int nitems = nrows * ng;
+        // accumulators of this thread's items start from the bias
+        float acc[kMaxItems][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = L.b[g * 8 + j];
-            for (int k = 0; k < kTaps; ++k) {
+        for (int it = 0; it < kMaxItems; ++it) {
+            const int item = tid + 256 * it;
+            const int g = (item < nitems) ? item % ng : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[it][j] = L.b[g * 8 + j];
+        }
+        // The layer's weights are staged ONE TAP at a time (cin x opad floats: 16 KB at 64 channels
+        // instead of 82 KB for all five), so that several workgroups fit a CU at every width.  The
+        // accumulation order (tap outer, in-channel inner) is the one the single-stage version had.
+#pragma unroll 1
+        for (int k = 0; k < kTaps; ++k) {
+            __syncthreads(); // previous tap / layer done with wbuf, `in` complete
+            const float* wsrc = L.w + (size_t)k * L.cin * L.opad;
+            for (int i = tid * 4; i < L.cin * L.opad; i += 256 * 4)
+                *reinterpret_cast<float4*>(wbuf + i) = *reinterpret_cast<const float4*>(wsrc + i);
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < kMaxItems; ++it) {
+                const int item = tid + 256 * it;
+                if (item >= nitems) continue;
+                const int r = rlo + item / ng, g = item % ng;
                 const float* arow = in + (r + k - kPad) * AS;
-                const float* wk = wbuf + (size_t)k * L.cin * L.opad + g * 8;
+                const float* wk = wbuf + g * 8;
                 for (int i = 0; i < L.cin; ++i) {
                     const float a = arow[i];
                     const float4 w0 = *reinterpret_cast<const float4*>(wk + i * L.opad);
                     const float4 w1 = *reinterpret_cast<const float4*>(wk + i * L.opad + 4);
-                    acc[0] = fmaf(a, w0.x, acc[0]); acc[1] = fmaf(a, w0.y, acc[1]);
-                    acc[2] = fmaf(a, w0.z, acc[2]); acc[3] = fmaf(a, w0.w, acc[3]);
-                    acc[4] = fmaf(a, w1.x, acc[4]); acc[5] = fmaf(a, w1.y, acc[5]);
-                    acc[6] = fmaf(a, w1.z, acc[6]); acc[7] = fmaf(a, w1.w, acc[7]);
+                    acc[it][0] = fmaf(a, w0.x, acc[it][0]); acc[it][1] = fmaf(a, w0.y, acc[it][1]);
+                    acc[it][2] = fmaf(a, w0.z, acc[it][2]); acc[it][3] = fmaf(a, w0.w, acc[it][3]);
+                    acc[it][4] = fmaf(a, w1.x, acc[it][4]); acc[it][5] = fmaf(a, w1.y, acc[it][5]);
+                    acc[it][6] = fmaf(a, w1.z, acc[it][6]); acc[it][7] = fmaf(a, w1.w, acc[it][7]);
                 }
             }
+        }
+#pragma unroll
+        for (int it = 0; it < kMaxItems; ++it) {
+            const int item = tid + 256 * it;
+            if (item >= nitems) continue;
+            const int r = rlo + item / ng, g = item % ng;
             const int t = tbase + r;
             const bool inside = (t >= 0 && t < T);
             if (l < 3) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    out[r * AS + g * 8 + j] = inside ? fmaxf(acc[j], 0.f) : 0.f;
+                    out[r * AS + g * 8 + j] = inside ? fmaxf(acc[it][j], 0.f) : 0.f;
             } else if (inside) {
                 float* yr = y + (b * (int64_t)T + t) * kOutCh + g * 8;
                 const bool dead = (int64_t)t >= nvalid;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (g * 8 + j < kOutCh) {
-                        float v = acc[j];
+                        float v = acc[it][j];
                         if (fa.flags & kPostDenorm) v *= fa.factor; // traintest.py:387-388
                         yr[j] = dead ? 0.f : v;                     // utils.py:309-312
                     }
