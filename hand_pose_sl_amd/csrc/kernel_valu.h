@@ -64,21 +64,23 @@ __global__ __launch_bounds__(256) void b2h_fwd_f32_valu(const float* __restrict_
     int64_t nvalid = T;
     if ((fa.flags & kPostMask) && fa.n_frames) nvalid = fa.n_frames[b];
 
-    constexpr int kMaxItems = 3; // (rows, 8-channel group) items per thread: <= 76 rows x 8 groups / 256 threads
+    // work item = TWO consecutive rows x one 8-channel group (nrows is even in every layer): each
+    // pair of float4 weight reads feeds 16 FMAs.  <= 38 row pairs x 8 groups / 256 threads = 2 items.
+    constexpr int kMaxItems = 2;
 #pragma unroll 1
     for (int l = 0; l < 4; ++l) {
         const ValuLayer L = p.L[l];
         const int ng = L.opad / 8;
         const int rlo = 2 * (l + 1), nrows = kValuRows - 4 * (l + 1);
-        const int nitems = nrows * ng;
+        const int nitems = (nrows / 2) * ng;
         // accumulators of this thread's items start from the bias
-        float acc[kMaxItems][8];
+        float acc[kMaxItems][2][8];
 #pragma unroll
         for (int it = 0; it < kMaxItems; ++it) {
             const int item = tid + 256 * it;
             const int g = (item < nitems) ? item % ng : 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[it][j] = L.b[g * 8 + j];
+            for (int j = 0; j < 8; ++j) acc[it][0][j] = acc[it][1][j] = L.b[g * 8 + j];
         }
         // The layer's weights are staged ONE TAP at a time (cin x opad floats: 16 KB at 64 channels
         // instead of 82 KB for all five), so that several workgroups fit a CU at every width.  The
@@ -94,17 +96,19 @@ __global__ __launch_bounds__(256) void b2h_fwd_f32_valu(const float* __restrict_
             for (int it = 0; it < kMaxItems; ++it) {
                 const int item = tid + 256 * it;
                 if (item >= nitems) continue;
-                const int r = rlo + item / ng, g = item % ng;
+                const int r = rlo + 2 * (item / ng), g = item % ng;
                 const float* arow = in + (r + k - kPad) * AS;
                 const float* wk = wbuf + g * 8;
                 for (int i = 0; i < L.cin; ++i) {
-                    const float a = arow[i];
+                    const float a0 = arow[i], a1 = arow[AS + i];
                     const float4 w0 = *reinterpret_cast<const float4*>(wk + i * L.opad);
                     const float4 w1 = *reinterpret_cast<const float4*>(wk + i * L.opad + 4);
-                    acc[it][0] = fmaf(a, w0.x, acc[it][0]); acc[it][1] = fmaf(a, w0.y, acc[it][1]);
-                    acc[it][2] = fmaf(a, w0.z, acc[it][2]); acc[it][3] = fmaf(a, w0.w, acc[it][3]);
-                    acc[it][4] = fmaf(a, w1.x, acc[it][4]); acc[it][5] = fmaf(a, w1.y, acc[it][5]);
-                    acc[it][6] = fmaf(a, w1.z, acc[it][6]); acc[it][7] = fmaf(a, w1.w, acc[it][7]);
+                    const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        acc[it][0][j] = fmaf(a0, w[j], acc[it][0][j]);
+                        acc[it][1][j] = fmaf(a1, w[j], acc[it][1][j]);
+                    }
                 }
             }
         }
@@ -112,23 +116,27 @@ __global__ __launch_bounds__(256) void b2h_fwd_f32_valu(const float* __restrict_
         for (int it = 0; it < kMaxItems; ++it) {
             const int item = tid + 256 * it;
             if (item >= nitems) continue;
-            const int r = rlo + item / ng, g = item % ng;
-            const int t = tbase + r;
-            const bool inside = (t >= 0 && t < T);
-            if (l < 3) {
+            const int g = item % ng;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    out[r * AS + g * 8 + j] = inside ? fmaxf(acc[it][j], 0.f) : 0.f;
-            } else if (inside) {
-                float* yr = y + (b * (int64_t)T + t) * kOutCh + g * 8;
-                const bool dead = (int64_t)t >= nvalid;
+            for (int h = 0; h < 2; ++h) {
+                const int r = rlo + 2 * (item / ng) + h;
+                const int t = tbase + r;
+                const bool inside = (t >= 0 && t < T);
+                if (l < 3) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (g * 8 + j < kOutCh) {
-                        float v = acc[it][j];
-                        if (fa.flags & kPostDenorm) v *= fa.factor; // traintest.py:387-388
-                        yr[j] = dead ? 0.f : v;                     // utils.py:309-312
-                    }
+                    for (int j = 0; j < 8; ++j)
+                        out[r * AS + g * 8 + j] = inside ? fmaxf(acc[it][h][j], 0.f) : 0.f;
+                } else if (inside) {
+                    float* yr = y + (b * (int64_t)T + t) * kOutCh + g * 8;
+                    const bool dead = (int64_t)t >= nvalid;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (g * 8 + j < kOutCh) {
+                            float v = acc[it][h][j];
+                            if (fa.flags & kPostDenorm) v *= fa.factor; // traintest.py:387-388
+                            yr[j] = dead ? 0.f : v;                     // utils.py:309-312
+                        }
+                }
             }
         }
         float* tmp = in; in = out; out = tmp;
