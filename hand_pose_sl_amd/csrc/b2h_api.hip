@@ -296,10 +296,15 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         const int64_t grid = B * tiles;
         if (grid > 0x7fffffff) return fail(B2H_ERR_SHAPE, "B*T too large for one launch");
         const size_t lds = ((size_t)2 * kValuRows * m->vp.act_stride + m->vp.wbuf_floats) * 4;
-        int rc = ensure_lds(m, 0, b2h_fwd_f32_valu, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(b2h_fwd_f32_valu, dim3((unsigned)grid), dim3(256), lds, st, x, y, (int)T, tiles,
-                           m->vp, fa);
+        if (m->C > 56) {
+            int rc = ensure_lds(m, 0, b2h_fwd_f32_valu<true>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(b2h_fwd_f32_valu<true>, dim3((unsigned)grid), dim3(256), lds, st, x, y, (int)T, tiles, m->vp, fa);
+        } else {
+            int rc = ensure_lds(m, 0, b2h_fwd_f32_valu<false>, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(b2h_fwd_f32_valu<false>, dim3((unsigned)grid), dim3(256), lds, st, x, y, (int)T, tiles, m->vp, fa);
+        }
     } else {
         // chunk length of the wave-per-chunk kernels: 112 frames (the LDS image's capacity) unless
         // that leaves most of the chip's wave slots idle (2 workgroups x 4 waves per CU); then 64 or

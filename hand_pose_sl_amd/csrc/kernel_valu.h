@@ -16,6 +16,7 @@ namespace b2h {
 constexpr int kValuTile = 64;
 constexpr int kValuRows = kValuTile + 2 * kHalo; // 80
 
+template <bool WIDE> // WIDE: in-channel loop unrolled by 4 -- pays at 57..64 channels (7.9 -> 5.8 ms at C = 64), costs 10 % at 30
 __global__ __launch_bounds__(256) void b2h_fwd_f32_valu(const float* __restrict__ x,
                                                         float* __restrict__ y, int T,
                                                         int tiles_per_seq, ValuParams p,
@@ -99,17 +100,24 @@ __global__ __launch_bounds__(256) void b2h_fwd_f32_valu(const float* __restrict_
                 const int r = rlo + 2 * (item / ng), g = item % ng;
                 const float* arow = in + (r + k - kPad) * AS;
                 const float* wk = wbuf + g * 8;
-                for (int i = 0; i < L.cin; ++i) {
-                    const float a0 = arow[i], a1 = arow[AS + i];
-                    const float4 w0 = *reinterpret_cast<const float4*>(wk + i * L.opad);
-                    const float4 w1 = *reinterpret_cast<const float4*>(wk + i * L.opad + 4);
-                    const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        acc[it][0][j] = fmaf(a0, w[j], acc[it][0][j]);
-                        acc[it][1][j] = fmaf(a1, w[j], acc[it][1][j]);
-                    }
+#define B2H_VALU_CHANNEL(i)                                                                   \
+    {                                                                                         \
+        const float a0 = arow[i], a1 = arow[AS + (i)];                                        \
+        const float4 w0 = *reinterpret_cast<const float4*>(wk + (i) * L.opad);                \
+        const float4 w1 = *reinterpret_cast<const float4*>(wk + (i) * L.opad + 4);            \
+        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};                  \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                       \
+            acc[it][0][j] = fmaf(a0, w[j], acc[it][0][j]);                                    \
+            acc[it][1][j] = fmaf(a1, w[j], acc[it][1][j]);                                    \
+        }                                                                                     \
+    }
+                if constexpr (WIDE) {
+#pragma unroll 4
+                    for (int i = 0; i < L.cin; ++i) B2H_VALU_CHANNEL(i)
+                } else {
+                    for (int i = 0; i < L.cin; ++i) B2H_VALU_CHANNEL(i)
                 }
+#undef B2H_VALU_CHANNEL
             }
         }
 #pragma unroll
