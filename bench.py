@@ -2,6 +2,7 @@
 """bench.py -- throughput of the body->hand hot path on N MI355X of one node.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3         # spawns the 8 ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,19 +14,32 @@ frames per GPU per step (1024 batches of config 3's batch=256; 13.8 GB of HBM
 traffic per step, far beyond the 256 MiB Infinity Cache; a step lasts ~3 ms so
 that the GPU's clock/power transient at the start of sustained load does not
 dominate short runs), sequence-sharded across ranks with no data-path collective
-(weak scaling).  The metric "hand-crops/sec"
-of BASELINE.json is reported as frames/s: the reference has no image crops, one
-"crop" = one frame of 12x2 body keypoints in -> 21x2 hand keypoints out
-(SURVEY.md section 0).
+(weak scaling).  The metric "hand-crops/sec" of BASELINE.json is reported as
+frames/s: the reference has no image crops, one "crop" = one frame of 12x2 body
+keypoints in -> 21x2 hand keypoints out.
 
-Rank 0 prints ONE JSON line (see the repo's task contract), with two extra
-objects: "roofline" (HIP-event launch time of the kernel vs HBM peak) and
-"cpu_baseline" (the reference's CPU execution -- four torch Conv1d calls --
-timed on this box's host cores; reported only).
+N > 1: one process per GPU over RCCL (torch.distributed backend "nccl").  Run from a
+plain shell with --gpus N the script starts the N ranks itself (a child
+`python -m torch.distributed.run`, before this process has touched the GPU) and relays
+rank 0's line.  RCCL is mandatory: if it cannot initialise, or two ranks sit on the same
+GPU, the run FAILS (non-zero exit, no line); `--backend gloo` exists only to rehearse the
+N > 1 plumbing on a one-GPU box and says so in the line.  For N > 1 the hand-back of the
+keypoints to rank 0 (north_star: "RCCL over xGMI used only to gather per-frame keypoints
+back to rank 0") is timed too and reported in the `gather` object, incl. and excl. the
+transfer; `value` stays the exchange-free compute rate.
+
+Rank 0 prints ONE JSON line (see the repo's task contract), with extra objects:
+"roofline" (HIP-event launch time of the headline kernel vs HBM peak), "kernels" (the same
+graded figures for every precision of the path, each with its error on the CPU sample),
+"cpu_baseline" (the reference's CPU execution -- four torch Conv1d calls -- timed on this
+box's host cores; reported only) and, for N > 1, "gather".
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,11 +50,14 @@ if ROOT not in sys.path:
 BYTES_PER_FRAME = 264      # 24 fp32 in + 42 fp32 out; weights 76 KB amortised
 FLOP_PER_FRAME = 37800     # 18 900 MAC
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16x3": 2500.0 / 3, "f32_mfma": 157.3, "f32_valu": 157.3, "fp32": 157.3}  # f16x3: three f16 MFMAs per product
+# dense matrix peak per precision (MI355X_MICROARCH.md); f16x3 issues three f16 MFMAs per product
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16x3": 2500.0 / 3, "f32_mfma": 157.3, "f32_valu": 157.3, "fp32": 157.3}
 DTYPE = {"bf16": "bf16", "f16": "f16", "f16x3": "f16x3 (f16 hi+lo operands, fp32-grade)", "f32_mfma": "f32", "f32_valu": "f32", "fp32": "f32"}
+TRAFFIC_JSON = os.path.join("profiles", "r2_final", "traffic.json")
+TRAFFIC_SOURCES = [os.path.join("hand_pose_sl_amd", "csrc", f) for f in ("kernel_mfma16.h", "kernel_mfma.h", "b2h_common.h", "b2h_api.hip")]
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -51,16 +68,76 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on a 1-GPU box)")
-    ap.add_argument("--gather", action="store_true",
-                    help="also time handing a config-4 stream (2000 seq) back to rank 0 (reported aside)")
-    return ap.parse_args()
+                    help="torch.distributed backend (nccl = RCCL, mandatory on a real node; gloo ONLY to rehearse "
+                         "N>1 on a one-GPU box)")
+    ap.add_argument("--gather-seqs", type=int, default=0,
+                    help="sequences per GPU in the pipelined hand-back measurement (0 = the bench shard, "
+                         "reduced to what fits rank 0's memory; 2048 under gloo)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the hand-back measurement (N > 1)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group even for one rank (smoke test of RCCL on a one-GPU box)")
+    return ap.parse_args(argv)
+
+
+def sources_sha256():
+    """Fingerprint of the sources the committed PMC traffic figure was measured on."""
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def committed_traffic(S, T, kernel_name, precision, path=None):
+    """HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/profile.sh):
+    counters cannot be read inside a bench run, so the committed figure for this exact workload
+    is reported -- only while the kernel sources still hash to what it was measured on; null for
+    any other configuration or after any edit of those sources."""
+    r = {"traffic": None}
+    try:
+        tj = json.load(open(path or os.path.join(ROOT, TRAFFIC_JSON)))
+        if (tj["seqs_per_gpu"], tj["frames_per_seq"]) == (S, T) and tj["kernel"] in kernel_name \
+                and tj["precision"] == precision:
+            if tj.get("sources_sha256") == sources_sha256():
+                r["traffic"] = tj["traffic_bytes"]
+                r["traffic_source"] = TRAFFIC_JSON
+            else:
+                r["traffic_note"] = f"{TRAFFIC_JSON} was measured on other kernel sources (sha256 mismatch): not reported"
+    except (OSError, KeyError, ValueError):
+        pass
+    return r
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) from a plain shell: start the N ranks as a CHILD
+    `python -m torch.distributed.run` and relay rank 0's JSON line.  This process never
+    touches the GPU (no torch import at all), so nothing that has initialised HIP is ever
+    re-executed."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("[bench] self-launch: " + " ".join(cmd) + "\n")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, cwd=ROOT)
+    lines = [ln for ln in r.stdout.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    if r.returncode != 0:
+        sys.stderr.write(f"[bench] a rank failed (torch.distributed.run exit code {r.returncode})\n")
+        sys.exit(r.returncode if 0 < r.returncode < 256 else 1)
+    if not lines:
+        sys.stderr.write("[bench] the ranks exited cleanly but rank 0 printed no line\n")
+        sys.exit(1)
+    sys.exit(0)
 
 
 def cpu_baseline(model, seconds):
     """Reference CPU path (torch Conv1d x4 == oracle.torch_port) on the host cores,
-    bounded sample: config 2/3-sized batches (256 x 200 frames) repeated for ~`seconds`."""
-    import numpy as np
+    bounded sample: config 2/3-sized batches (256 x 200 frames) repeated for ~`seconds`.
+    Returns the baseline object, the sample and the CPU result (for the per-kernel error)."""
     import torch
 
     import oracle
@@ -94,62 +171,106 @@ def cpu_baseline(model, seconds):
         if el >= seconds or n >= 200000:
             break
     fps = n * 256 * 200 / el
-    # the same sample through the HIP path, checked against the CPU result
-    import torch as _t
-    with _t.no_grad():
-        y_gpu = model(x.to(next(model.parameters()).device)).cpu()
-    err = float((y_gpu - y_cpu.contiguous()).abs().max())
-    return {"value": fps, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"(256,200,12,2) U[-0.5,0.5] x {n} passes in {el:.1f} s, torch {torch.__version__} "
-                      f"Conv1d x4 fp32 (oracle/torch_port.py), best of 1/8/16 threads (host share of one GPU)",
-            "gflops": fps * FLOP_PER_FRAME / 1e9, "gpu_max_abs_err_on_sample": err}
+    out = {"value": fps, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"(256,200,12,2) U[-0.5,0.5] x {n} passes in {el:.1f} s, torch {torch.__version__} "
+                     f"Conv1d x4 fp32 (oracle/torch_port.py), best of 1/8/16 threads (host share of one GPU)",
+           "gflops": fps * FLOP_PER_FRAME / 1e9}
+    return out, x, y_cpu.contiguous()
+
+
+def kernel_roofline(model, x, y, prec, iters):
+    """Graded figures of one precision of the path on the bench shard: HIP events on the launch
+    stream (b2h_time_forward), algorithmic bytes and FLOPs per launch, both ceilings; `bound` is
+    the ceiling that is lower in frames/s for that arithmetic."""
+    S, T = x.shape[0], x.shape[1]
+    ms = model.time_forward(x, y, iters, precision=prec)
+    gbs = S * T * BYTES_PER_FRAME / (ms * 1e-3) / 1e9
+    tfl = S * T * FLOP_PER_FRAME / (ms * 1e-3) / 1e12
+    peak_t = MFMA_PEAK_TFLOPS[prec]
+    hbm_bound = (HBM_PEAK_GBS * 1e9 / BYTES_PER_FRAME) <= (peak_t * 1e12 / FLOP_PER_FRAME)
+    r = {"kernel": model.kernel_name(prec), "dtype": DTYPE[prec], "launch_ms": ms, "launches_timed": iters,
+         "frames_per_s": S * T / (ms * 1e-3), "bytes_per_launch": S * T * BYTES_PER_FRAME,
+         "flop_per_launch": S * T * FLOP_PER_FRAME,
+         "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+         "mfma_tflops": tfl, "mfma_peak_tflops": peak_t, "mfma_frac": tfl / peak_t}
+    if hbm_bound:
+        r.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
+    else:
+        r.update(bound="mfma", achieved=tfl, peak=peak_t, unit="TFLOP/s", frac=tfl / peak_t)
+    return r
+
+
+def gpu_identity(torch, dev):
+    p = torch.cuda.get_device_properties(dev)
+    ident = {"index": dev.index, "name": p.name,
+             "pci": f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"}
+    try:
+        ident["uuid"] = str(p.uuid)
+    except Exception:  # noqa: BLE001 -- older builds have no uuid field
+        pass
+    return ident
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        self_launch(args, sys.argv[1:])          # does not return
     # Rank 0 prints exactly ONE line on stdout: the JSON.  Libraries underneath (RCCL's version
     # banner, gloo's connection notes, hipcc when the extension is rebuilt) write to fd 1 as they
     # please, so fd 1 is pointed at stderr for the whole run and the JSON goes to the saved descriptor.
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    import datetime
+
     import torch
     import torch.distributed as dist
 
     import hand_pose_sl_amd as hps
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.stderr.write(f"[bench rank {rank}] --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}\n")
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU path in the product)")
     ndev = torch.cuda.device_count()
-    dev_index = local_rank % ndev          # one rank per GPU on a real node; wraps only in 1-GPU rehearsals
+    backend = None
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)          # only missing for a lone --force-dist rank
+        backend = args.backend
+        if backend == "nccl" and ndev < world:
+            sys.exit(f"bench.py --gpus {world}: only {ndev} GPU(s) visible; one rank per GPU over RCCL is required "
+                     f"(use --backend gloo only to rehearse the plumbing on a one-GPU box)")
+    dev_index = local_rank % ndev          # one rank per GPU on a real node; wraps only in gloo rehearsals
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    backend = None
-    if world > 1:
-        # The collectives here are control traffic only (barrier + max of the elapsed time): the
-        # data path is sequence-sharded with no exchange.  RCCL by default; if it cannot initialise
-        # on this node the run falls back to gloo (host tensors) rather than losing the bench line.
-        backend = args.backend
+    gpus = [gpu_identity(torch, dev)]
+    if use_dist:
+        # RCCL carries the barrier, the max of the elapsed time, the GPU census and the keypoint
+        # hand-back.  No fallback: an RCCL failure ends the run with a non-zero exit code.
         if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=dev)
-                probe = torch.zeros(1, device=dev)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-            except Exception as exc:  # noqa: BLE001 -- any RCCL failure
-                sys.stderr.write(f"[bench rank {rank}] RCCL unavailable ({type(exc).__name__}: {exc}); using gloo\n")
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-        if backend == "gloo":
-            dist.init_process_group("gloo")
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                sys.exit(f"[bench rank {rank}] RCCL all_reduce probe returned {probe.item()} for world {world}")
+        else:
+            sys.stderr.write(f"[bench rank {rank}] --backend gloo: REHEARSAL of the {world}-rank plumbing, "
+                             f"not an xGMI measurement\n")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
+        census = [None] * world
+        dist.all_gather_object(census, gpus[0])
+        gpus = census
+        distinct = len({g.get("uuid") or g["pci"] for g in gpus})
+        if backend == "nccl" and distinct != world:
+            sys.exit(f"[bench rank {rank}] {world} ranks on {distinct} distinct GPU(s): {gpus}")
 
     S, T = args.seqs, args.frames
     torch.manual_seed(0)
@@ -161,9 +282,16 @@ def main():
     y = torch.empty((S, T, 21, 2), dtype=torch.float32, device=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if not use_dist:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     import ctypes
 
@@ -183,11 +311,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el = max_over_ranks(time.perf_counter() - t0)
 
     frames_total = S * T * world * args.steps
     value = frames_total / el
@@ -198,78 +322,105 @@ def main():
         "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
         "config": {"workload": f"BASELINE config 3 stream: ConvModel(30,'ReLU',pos_emb=False) {args.precision} "
                                f"path, {S} seq x {T} frames per GPU per step, inputs resident in HBM, "
-                               f"sequence-sharded, no data-path collective",
+                               f"sequence-sharded, no data-path collective in `value`",
                    "seqs_per_gpu": S, "frames_per_seq": T, "kernel": model.kernel_name(),
-                   "parallelism": f"seq-shard x{world}"},
+                   "parallelism": f"seq-shard x{world}", "gpus": gpus},
     }
     if backend is not None:
-        out["config"]["control_backend"] = backend  # barrier + max(elapsed) only
+        out["config"]["backend"] = "rccl" if backend == "nccl" else "gloo (REHEARSAL on shared GPUs, not xGMI)"
 
     if rank == 0:
         # roofline of the dominant (only) kernel: HIP events on the launch stream
         iters = max(5, min(args.steps, 50))
-        ms = model.time_forward(x, y, iters)
-        alg_bytes = S * T * BYTES_PER_FRAME
-        gbs = alg_bytes / (ms * 1e-3) / 1e9
-        tfl = S * T * FLOP_PER_FRAME / (ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                           "kernel": model.kernel_name(), "launch_ms": ms, "launches_timed": iters,
-                           "bytes_per_launch": alg_bytes,
-                           "mfma_tflops": tfl, "mfma_peak_tflops": MFMA_PEAK_TFLOPS[args.precision],
-                           "mfma_frac": tfl / MFMA_PEAK_TFLOPS[args.precision]}
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/profile.sh):
-        # counters cannot be read inside this run, so the committed figure for this exact
-        # workload and kernel is reported; null for any other configuration.
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_final", "traffic.json")))
-            if (tj["seqs_per_gpu"], tj["frames_per_seq"]) == (S, T) and tj["kernel"] in model.kernel_name() \
-                    and tj["precision"] == args.precision:
-                out["roofline"]["traffic"] = tj["traffic_bytes"]
-                out["roofline"]["traffic_source"] = "profiles/r1_final/traffic.json"
-        except (OSError, KeyError, ValueError):
-            pass
+        rf = kernel_roofline(model, x, y, args.precision, iters)
+        rf.update(committed_traffic(S, T, model.kernel_name(), args.precision))
+        out["roofline"] = rf
+
+    # ---- N > 1: the hand-back of the keypoints to rank 0, timed (never part of `value`) ----------
+    if world > 1 and not args.no_gather:
+        from hand_pose_sl_amd.stream import ShardedStream, shard_bounds
+        stream = ShardedStream(model)
+        gat = {"backend": "rccl" if backend == "nccl" else "gloo (rehearsal)",
+               "transport": "direct peer->root send/recv (grouped per piece), no ring"}
+
+        def timed(fn, reps, warm):
+            for _ in range(warm):
+                fn()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            barrier()
+            return max_over_ranks(time.perf_counter() - t0) / reps
+
+        # (1) the bench shard, handed back piece by piece while the next piece computes
+        Sg = args.gather_seqs or (S if backend == "nccl" else min(S, 2048))
+        Sg = min(Sg, S)
+        if rank == 0:
+            free, _tot = torch.cuda.mem_get_info(dev)
+            while Sg > 1024 and world * Sg * T * 168 * 1.15 > free:
+                Sg //= 2
+        sg_t = torch.tensor([Sg], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.broadcast(sg_t, 0)
+        Sg = int(sg_t.item())
+        pieces = 8
+        chunk = max(1, (Sg + pieces - 1) // pieces)
+        xs = x[:Sg]
+        n_tot = Sg * world
+        res = {}
+        t_incl = timed(lambda: res.__setitem__("y", stream.run_pipelined(xs, n_tot, chunk)), 3, 1)
+        res.clear()
+        torch.cuda.empty_cache()
+        t_excl = timed(lambda: [model.forward_into(xs[a:a + chunk], y[a:a + chunk]) for a in range(0, Sg, chunk)], 3, 1)
+        into0 = (n_tot - Sg) * T * 168
+        gat["pipelined"] = {"workload": f"bench shard: {Sg} seq x {T} frames per GPU in {pieces} pieces, piece k handed "
+                                        f"to rank 0 while piece k+1 computes",
+                            "seqs_per_gpu": Sg, "ms_incl": t_incl * 1e3, "ms_excl": t_excl * 1e3,
+                            "frames_per_s_incl": n_tot * T / t_incl, "frames_per_s_excl": n_tot * T / t_excl,
+                            "bytes_into_rank0": into0, "rank0_ingest_GBps": into0 / t_incl / 1e9}
+        # (2) BASELINE config 4: 2 000 sequences over the ranks, one gather at the end
+        n4 = 2000
+        lo, hi = shard_bounds(n4, rank, world)
+        x4 = x[: hi - lo]
+        t4_incl = timed(lambda: stream.run(x4, n4, gather=True), 20, 3)
+        t4_excl = timed(lambda: stream.run(x4, n4, gather=False), 20, 3)
+        into0 = (n4 - (shard_bounds(n4, 0, world)[1])) * T * 168
+        gat["config4"] = {"workload": f"BASELINE config 4: {n4} seq x {T} frames sharded over {world} GPUs, keypoints "
+                                      f"gathered to rank 0",
+                          "ms_incl": t4_incl * 1e3, "ms_excl": t4_excl * 1e3,
+                          "frames_per_s_incl": n4 * T / t4_incl, "frames_per_s_excl": n4 * T / t4_excl,
+                          "bytes_into_rank0": into0}
+        out["gather"] = gat
 
     if rank == 0 and world == 1:
-        # informational: the same shard through the fp32-grade and the exact-fp32 kernels (a few
-        # launches each; not part of `value`)
-        other = {}
-        for prec, it in (("f16x3", 5), ("f32_mfma", 3)):
-            if prec == args.precision:
+        # the same shard through every other precision of the path, graded the same way
+        kernels = {args.precision: dict(out["roofline"])}
+        for prec, it in (("bf16", 10), ("f16", 10), ("f16x3", 5), ("f32_mfma", 3)):
+            if prec in kernels:
                 continue
             try:
-                ms_o = model.time_forward(x, y, it, precision=prec)
-                other[prec] = {"launch_ms": ms_o, "frames_per_s": S * T / (ms_o * 1e-3), "kernel": model.kernel_name(prec)}
+                kernels[prec] = kernel_roofline(model, x, y, prec, it)
             except RuntimeError as exc:
-                other[prec] = {"error": str(exc)}
-        out["other_kernels"] = other
-
-    if args.gather and world >= 1:
-        from hand_pose_sl_amd.stream import ShardedStream, shard_bounds
-        n_seq = 2000
-        lo, hi = shard_bounds(n_seq, rank, world)
-        stream = ShardedStream(model)
-        xs = x[: hi - lo]
-        for _ in range(2):
-            stream.run(xs, n_seq, gather=True)
-        barrier()
-        t0 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
-            stream.run(xs, n_seq, gather=True)
-        barrier()
-        eg = (time.perf_counter() - t0) / reps
-        if rank == 0:
-            out["gather"] = {"workload": "config 4: 2000 seq x 200 frames sharded, keypoints handed back to rank 0",
-                             "ms": eg * 1e3, "frames_per_s": n_seq * T / eg}
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model, args.cpu_seconds)
+                kernels[prec] = {"error": str(exc)}
+        out["kernels"] = kernels
+        if not args.no_cpu_baseline:
+            cb, xs_cpu, y_cpu = cpu_baseline(model, args.cpu_seconds)
+            # the same sample through the HIP path, every precision, checked against the CPU result
+            xd = xs_cpu.to(dev)
+            yd = torch.empty((xd.shape[0], xd.shape[1], 21, 2), dtype=torch.float32, device=dev)
+            for prec, rec in kernels.items():
+                if "error" in rec:
+                    continue
+                model.forward_into(xd, yd, precision=prec)
+                rec["gpu_max_abs_err_on_sample"] = float((yd.cpu() - y_cpu).abs().max())
+            cb["gpu_max_abs_err_on_sample"] = kernels[args.precision]["gpu_max_abs_err_on_sample"]
+            out["roofline"]["gpu_max_abs_err_on_sample"] = cb["gpu_max_abs_err_on_sample"]
+            out["cpu_baseline"] = cb
 
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

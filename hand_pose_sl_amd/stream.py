@@ -92,7 +92,12 @@ class ShardedStream:
         """Like run(gather=True), but the shard is processed in `chunk`-sequence pieces and each
         piece is handed to root as soon as it is computed: the transfer of piece k (RCCL runs it
         on its own stream) overlaps the kernel of piece k+1.  Returns the full (n_seq, T, 21, 2)
-        result on root, None elsewhere; bit-identical to run()."""
+        result on root, None elsewhere; bit-identical to run().
+
+        Every rank walks the same piece index k.  Per piece a peer posts ONE grouped send and root
+        ONE grouped batch of receives, one per peer that still has a piece k
+        (`dist.batch_isend_irecv` = ncclGroupStart/End around the send/recv calls), so RCCL sees
+        matched groups in the same order on both sides of every pair."""
         if self.world == 1:
             return self.run_local(x_local)
         sizes = shard_sizes(n_seq, self.world)
@@ -104,23 +109,27 @@ class ShardedStream:
             return dist.get_global_rank(self.group, r) if self.group is not None else r
 
         reqs, keep, out = [], [], None
+        bounds = [shard_bounds(n_seq, r, self.world) for r in range(self.world)]
+        lo, hi = bounds[self.rank]
         if self.rank == root:
             T = x_local.shape[1]
             out = torch.empty((n_seq, T, 21, 2), dtype=torch.float32, device=x_local.device)
-            for r in range(self.world):        # post every receive up front, piece by piece
-                if r == root:
-                    continue
-                lo, hi = shard_bounds(n_seq, r, self.world)
-                for a in range(lo, hi, chunk):
-                    reqs.append(dist.irecv(out[a:min(a + chunk, hi)], peer(r), group=self.group))
-        lo, hi = shard_bounds(n_seq, self.rank, self.world)
-        for a in range(0, hi - lo, chunk):
-            y = self.model(x_local[a:a + chunk]).contiguous()
+        for a in range(0, max(sizes), chunk):
+            ops = []
+            if a < hi - lo:
+                y = self.model(x_local[a:a + chunk]).contiguous()
+                if self.rank == root:
+                    out[lo + a:lo + a + y.shape[0]].copy_(y)
+                else:
+                    keep.append(y)                 # keep the buffer alive until its send completes
+                    ops.append(dist.P2POp(dist.isend, y, peer(root), self.group))
             if self.rank == root:
-                out[lo + a:lo + a + y.shape[0]].copy_(y)
-            else:
-                keep.append(y)                 # keep the buffer alive until its send completes
-                reqs.append(dist.isend(y, peer(root), group=self.group))
+                for r in range(self.world):
+                    if r != root and a < sizes[r]:
+                        rlo, rhi = bounds[r]
+                        ops.append(dist.P2POp(dist.irecv, out[rlo + a:min(rlo + a + chunk, rhi)], peer(r), self.group))
+            if ops:
+                reqs.extend(dist.batch_isend_irecv(ops))
         for r in reqs:
             r.wait()
         return out

@@ -49,6 +49,8 @@ def test_host_program_matches_reference(name, kernel, tmp_path, cuda_device):
     r = subprocess.run([exe, str(inp), str(out), str(kernel)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     y = np.fromfile(out, dtype=np.float32).reshape(rec["B"], rec["T"], 21, 2)
-    tol = {1: 2e-5, 2: 2e-5, 3: 1.5e-3, 4: 2.5e-4}[kernel]
+    # bf16: north_star's 1e-3 on normalised inputs; cfg1_b1_t200 is the N(0,1) exceedance case
+    # (test_gpu_parity.BF16_RANDN_BOUND, measured 1.047e-3)
+    tol = {1: 2e-5, 2: 2e-5, 3: 1.1e-3 if str(rec["kind"]) == "randn" else 1e-3, 4: 2.5e-4}[kernel]
     assert np.abs(y - rec["y"]).max() <= tol
     assert np.abs(y - oracle.forward_from_state(rec["x"], rec["state"], pos_emb=rec["pos_emb"])).max() <= tol

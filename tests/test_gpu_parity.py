@@ -4,10 +4,17 @@ the checker for inputs the fixtures do not hold.
 
 Tolerances (north_star: <= 1e-3 max-abs in fp32 vs the reference CPU forward):
   fp32 kernels  (VALU, exact-fp32 MFMA)  : 2e-5   (measured ~1e-7; summation order only)
-  bf16 MFMA                              : 1.5e-3 vs the fp32 reference (bf16 operand
-      rounding; SURVEY.md section 7 measures 5e-4..1.2e-3) AND 6e-4 vs the oracle's
-      bf16-operand model (fp32 summation order flips an occasional bf16 rounding of an
-      intermediate activation by one ulp = 2^-9 relative; measured <= 2e-4)
+  f16x3 (f16 hi/lo split)                : the same 2e-5 bar as fp32
+  bf16 MFMA                              : **1e-3** (north_star's bar) vs the fp32 reference on every
+      normalised-keypoint input -- U[0,1] ("u01", pixel/1280-like) and U[-.5,.5] ("u55",
+      dif-encoded-like), which is what the path is fed (measured 3.7-5.0e-4) -- AND 6e-4 vs the
+      oracle's bf16-operand model (fp32 summation order flips an occasional bf16 rounding of an
+      intermediate activation by one ulp = 2^-9 relative; measured <= 2e-4).
+      DOCUMENTED EXCEEDANCE: on unnormalised N(0,1) inputs ("randn" fixtures: |x| up to 4.5, which
+      keypoints/1280 never reach) bf16 operand rounding itself gives 1.047e-3 (the oracle's
+      bf16-operand model measures the same against the reference), i.e. 5 % over north_star's bar.
+      Those fixtures are held to the named bound BF16_RANDN_BOUND = 1.1e-3, not to a blanket
+      looser tolerance; callers that need <= 1e-3 on such inputs use f16 (1.2e-4) or f16x3 / fp32.
   f16 MFMA                               : 2.5e-4 vs fp32 reference, 8e-5 vs the f16 model
 """
 import numpy as np
@@ -20,7 +27,8 @@ from conftest import CONV_CASES, load_golden
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"f32_valu": 2e-5, "f32_mfma": 2e-5, "f16x3": 2e-5, "bf16": 1.5e-3, "f16": 2.5e-4}   # f16x3: the fp32 bar
+TOL = {"f32_valu": 2e-5, "f32_mfma": 2e-5, "f16x3": 2e-5, "bf16": 1e-3, "f16": 2.5e-4}   # f16x3: the fp32 bar
+BF16_RANDN_BOUND = 1.1e-3   # bf16 on N(0,1) inputs only (see the docstring): measured 1.047e-3
 TOL_MODEL = {"bf16": 6e-4, "f16": 8e-5}   # vs the oracle's operand-rounding model
 ORACLE_MODE = {"bf16": "bf16", "f16": "f16"}
 ALL_PREC = ["f32_valu", "f32_mfma", "f16x3", "bf16", "f16"]
@@ -34,6 +42,13 @@ def _model(rec, prec, dev):
 
 def _supported(rec, prec):
     return rec["C"] <= 32 or prec == "f32_valu"
+
+
+def _tol(rec, prec):
+    """north_star's 1e-3 for bf16 on normalised inputs; the named exceedance bound on randn fixtures."""
+    if prec == "bf16" and str(rec.get("kind")) == "randn":
+        return BF16_RANDN_BOUND
+    return TOL[prec]
 
 
 @pytest.mark.parametrize("prec", ALL_PREC)
@@ -53,11 +68,12 @@ def test_golden(name, prec, cuda_device):
     y = y.cpu().numpy()
     ys = y[rec["y_idx"]] if "y_idx" in rec else y
     err = np.abs(ys - rec["y"]).max()
-    assert err <= TOL[prec], f"{name}/{prec}: max-abs {err:.3e}"
+    tol = _tol(rec, prec)
+    assert err <= tol, f"{name}/{prec}: max-abs {err:.3e} (bar {tol:.1e}, input kind {rec.get('kind')})"
     # first / last 8 frames carry the per-layer zero padding (SURVEY.md section 7 hard part)
     if rec["T"] >= 16:
-        assert np.abs(ys[:, :8] - rec["y"][:, :8]).max() <= TOL[prec]
-        assert np.abs(ys[:, -8:] - rec["y"][:, -8:]).max() <= TOL[prec]
+        assert np.abs(ys[:, :8] - rec["y"][:, :8]).max() <= tol
+        assert np.abs(ys[:, -8:] - rec["y"][:, -8:]).max() <= tol
     if prec in ORACLE_MODE:
         ym = oracle.forward_from_state(rec["x"], rec["state"], pos_emb=rec["pos_emb"], mode=ORACLE_MODE[prec])
         errm = np.abs(y - ym).max()
@@ -100,6 +116,35 @@ def test_kernels_agree_and_batch_independent(prec, cuda_device):
     assert torch.equal(y[idx], y_small)
     ref = oracle.forward_from_state(x[idx].cpu().numpy(), rec["state"])
     assert np.abs(y_small.cpu().numpy() - ref).max() <= TOL[prec]
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16", "f16x3", "f32_mfma"])
+def test_config4_stream_sharded_equals_one_launch(prec, cuda_device):
+    """BASELINE config 4: 2 000 sequences x 200 frames, U[-.5,.5], seed 1234.
+    The stream in ONE launch must equal, bit for bit, the eight `shard_bounds(2000, r, 8)` shards
+    (250 sequences each) run separately and concatenated -- what the 8 ranks compute -- and the
+    2- and 4-rank partitions; a sample of sequences equals the oracle; and the single-rank
+    `ShardedStream` paths (run, run_pipelined) return the same tensor."""
+    from hand_pose_sl_amd.stream import ShardedStream, shard_bounds
+    rec = load_golden("cfg1_b1_t200")
+    g = torch.Generator().manual_seed(1234)
+    x = (torch.rand((2000, 200, 12, 2), generator=g) - 0.5).to(cuda_device)
+    m = _model(rec, prec, cuda_device)
+    with torch.no_grad():
+        y = m(x)
+        for world in (8, 4, 2):
+            parts = []
+            for r in range(world):
+                lo, hi = shard_bounds(2000, r, world)
+                assert world != 8 or hi - lo == 250
+                parts.append(m(x[lo:hi].contiguous()))
+            assert torch.equal(torch.cat(parts, dim=0), y), (prec, world)
+        stream = ShardedStream(m, max_batch=600)        # 2000 sequences = 4 launches of <= 600
+        assert torch.equal(stream.run(x, 2000, gather=True), y)
+        assert torch.equal(stream.run_pipelined(x, 2000, chunk=250), y)
+    idx = [0, 249, 250, 999, 1750, 1999]                  # shard edges of the 8-way partition
+    ref = oracle.forward_from_state(x[idx].cpu().numpy(), rec["state"])
+    assert np.abs(y[idx].cpu().numpy() - ref).max() <= TOL[prec]
 
 
 def test_module_surface(cuda_device):
