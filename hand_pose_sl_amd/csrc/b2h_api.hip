@@ -10,12 +10,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "b2h_common.h"
 #include "kernel_mfma.h"
 #include "kernel_mfma16.h"
+#include "kernel_mfma16w.h"
 #include "kernel_mfma3.h"
 #include "kernel_tenc.h"
 #include "kernel_valu.h"
@@ -80,6 +82,25 @@ int check_device(int model_device) {
     return B2H_OK;
 }
 
+// The model-free entry points (metric, target transform) have no device of their own: every pointer
+// must be non-NULL device memory of the CURRENT device, or the kernel would fault / run elsewhere.
+int check_device_ptr(const void* p, const char* name) {
+    if (!p) return fail(B2H_ERR_INVALID, std::string(name) + " is NULL");
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(B2H_ERR_INVALID, std::string(name) + " is not a device pointer");
+    }
+    if (a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeManaged)
+        return fail(B2H_ERR_INVALID, std::string(name) + " is not device memory");
+    if (a.device != cur)
+        return fail(B2H_ERR_INVALID, std::string(name) + " lives on HIP device " + std::to_string(a.device) +
+                                        ", the current device is " + std::to_string(cur));
+    return B2H_OK;
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -106,11 +127,11 @@ struct b2h_model {
     DevBuf mf32_w[4], m_bias[4];  // exact-fp32 MFMA kernel: per-layer fragments + bias fragments
     DevBuf m3_w[4];               // f16x3 kernel: per-layer hi / lo f16 fragments (bias shared)
     DevBuf mbf16_all, mf16_all;   // persistent 16-bit kernel: [W L0..L3 | bias L0..L3], kPacked16 bytes
+    DevBuf mwbf_w[4], mwh_w[4], mw_bias[4]; // wide 16-bit kernel (33..64 channels): bf16 / f16 fragments, bias
     int num_cus = 256;
     ValuParams vp;
-    MfmaParams mp32, mp3;
+    MfmaParams mp32, mp3, mpw_bf, mpw_h;
     float w_absmax = 0.f;         // largest |weight| or |bias| (NaN counts as inf): F16X3 needs < 65504
-    bool lds_attr_set[9] = {false, false, false, false, false, false, false, false, false};
 };
 
 namespace {
@@ -143,6 +164,40 @@ float absmax_of(const std::vector<float>& v, float acc) {
     return acc;
 }
 
+// Wide 16-bit kernel (kernel_mfma16w.h): per layer [mt][tap][ks][lane][8], in-position 32ks + 8q + j
+// (layer 1: the 24|25 inputs, pos_emb moved to slot 24; hidden layers: position = channel), out slot
+// (mt, row) = channel 16(row>>2) + 4mt + (row&3) (head: 16mt + row); bias [mt][q][4] fp32.
+int pack_wide(b2h_model* m, const HostWeights& hw) {
+    for (int l = 0; l < 4; ++l) {
+        const int MT = wide_mt(l), KS = wide_ks(l);
+        auto chan = [&](int mt, int row) { return l == 3 ? last_chan_of(mt, row) : wide_chan_of(mt, row); };
+        std::vector<uint16_t> wb((size_t)MT * kTaps * KS * 64 * 8), wh(wb.size());
+        for (int mt = 0; mt < MT; ++mt)
+            for (int k = 0; k < kTaps; ++k)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const float v = hw.at(l, chan(mt, lane & 15), 32 * ks + 8 * (lane >> 4) + j, k, true);
+                            const size_t idx = ((((size_t)mt * kTaps + k) * KS + ks) * 64 + lane) * 8 + j;
+                            wb[idx] = f32_to_bf16(v);
+                            wh[idx] = f32_to_f16(v);
+                        }
+        std::vector<float> bf((size_t)MT * 16);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int q = 0; q < 4; ++q)
+                for (int r = 0; r < 4; ++r) bf[(mt * 4 + q) * 4 + r] = hw.bias(l, chan(mt, 4 * q + r));
+        int rc;
+        if ((rc = m->mwbf_w[l].upload(wb.data(), wb.size() * 2))) return rc;
+        if ((rc = m->mwh_w[l].upload(wh.data(), wh.size() * 2))) return rc;
+        if ((rc = m->mw_bias[l].upload(bf.data(), bf.size() * 4))) return rc;
+        m->mpw_bf.w[l] = m->mwbf_w[l].p;
+        m->mpw_h.w[l] = m->mwh_w[l].p;
+        m->mpw_bf.bias[l] = m->mpw_h.bias[l] = (const float*)m->mw_bias[l].p;
+    }
+    m->mpw_bf.pos_emb = m->mpw_h.pos_emb = m->pos_emb;
+    return B2H_OK;
+}
+
 int pack_all(b2h_model* m, const HostWeights& hw) {
     m->w_absmax = 0.f;
     for (int l = 0; l < 4; ++l) m->w_absmax = absmax_of(hw.b[l], absmax_of(hw.w[l], m->w_absmax));
@@ -171,7 +226,7 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
         m->vp.wbuf_floats = wb;
         m->vp.pos_emb = m->pos_emb;
     }
-    if (m->C > kMfmaWidth) return B2H_OK; // MFMA kernels: conv_channels <= 32
+    if (m->C > kMfmaWidth) return pack_wide(m, hw); // 33..64 channels: the wide 16-bit kernel only
 
     // ---- MFMA layouts
     std::vector<unsigned char> ab(kPacked16, 0), ah(kPacked16, 0); // LDS images of the persistent kernel
@@ -243,20 +298,37 @@ int resolve_kernel(const b2h_model* m, int kernel) {
 bool kernel_ok(const b2h_model* m, int k) {
     switch (k) {
         case B2H_KERNEL_F32_VALU: return m->C <= kMaxWidth;
-        case B2H_KERNEL_F32_MFMA:
+        case B2H_KERNEL_F32_MFMA: return m->C <= kMfmaWidth;
         case B2H_KERNEL_BF16_MFMA:
-        case B2H_KERNEL_F16_MFMA: return m->C <= kMfmaWidth;
+        case B2H_KERNEL_F16_MFMA: return m->C <= kMaxWidth; // > 32 channels: the wide kernel
         case B2H_KERNEL_F16X3_MFMA: return m->C <= kMfmaWidth && (!m->has_weights || m->w_absmax < kF16Max);
         default: return false;
     }
 }
 
-template <typename K> int ensure_lds(b2h_model* m, int slot, K kern, size_t bytes) {
-    if (bytes > 64 * 1024 && !m->lds_attr_set[slot]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        m->lds_attr_set[slot] = true;
-    }
+// Every kernel that may use more than 64 KB of dynamic LDS gets its cap raised ONCE per device, when
+// weights are loaded -- not inside launch(), so that the very first b2h_forward is already free of
+// runtime calls other than the launch itself and can be captured into a HIP graph.
+template <typename K> int raise_lds_cap(K kern) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return B2H_OK;
+}
+
+int set_conv_kernel_attributes() {
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && done[dev]) return B2H_OK;
+    int rc;
+    if ((rc = raise_lds_cap(b2h_fwd_f32_valu<true>)) || (rc = raise_lds_cap(b2h_fwd_f32_valu<false>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma_f32)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, true>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, true>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_BF16>)) || (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_F16>)))
+        return rc;
+    if (dev >= 0 && dev < 64) done[dev] = true;
     return B2H_OK;
 }
 
@@ -297,12 +369,8 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         if (grid > 0x7fffffff) return fail(B2H_ERR_SHAPE, "B*T too large for one launch");
         const size_t lds = ((size_t)2 * kValuRows * m->vp.act_stride + m->vp.wbuf_floats) * 4;
         if (m->C > 56) {
-            int rc = ensure_lds(m, 0, b2h_fwd_f32_valu<true>, lds);
-            if (rc) return rc;
             hipLaunchKernelGGL(b2h_fwd_f32_valu<true>, dim3((unsigned)grid), dim3(256), lds, st, x, y, (int)T, tiles, m->vp, fa);
         } else {
-            int rc = ensure_lds(m, 0, b2h_fwd_f32_valu<false>, lds);
-            if (rc) return rc;
             hipLaunchKernelGGL(b2h_fwd_f32_valu<false>, dim3((unsigned)grid), dim3(256), lds, st, x, y, (int)T, tiles, m->vp, fa);
         }
     } else {
@@ -310,8 +378,9 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         // that leaves most of the chip's wave slots idle (2 workgroups x 4 waves per CU); then 64 or
         // 32 frames, paying the +-8-frame halo recompute for parallelism.  Any chunking computes
         // bit-identical frames.
+        const bool wide = m->C > kMfmaWidth; // 33..64 channels: wave-per-chunk 16-bit kernel (kernel_mfma16w.h)
         int chunk_len = kChunk;
-        if (k != B2H_KERNEL_BF16_MFMA && k != B2H_KERNEL_F16_MFMA) {
+        if (wide || (k != B2H_KERNEL_BF16_MFMA && k != B2H_KERNEL_F16_MFMA)) {
             const int64_t slots = (int64_t)m->num_cus * 2 * kWavesPerBlock;
             for (int cand : {64, 32}) {
                 if (B * ((T + chunk_len - 1) / chunk_len) * 2 >= slots) break;
@@ -323,15 +392,17 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         const int64_t grid = (nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
         if (grid > 0x7fffffff) return fail(B2H_ERR_SHAPE, "B*T too large for one launch");
         const dim3 g((unsigned)grid), blk(64 * kWavesPerBlock);
-        if (k == B2H_KERNEL_F32_MFMA) {
+        if (wide) {
+            const size_t lds = (size_t)kWavesPerBlock * kImgW;
+            if (k == B2H_KERNEL_BF16_MFMA)
+                hipLaunchKernelGGL(b2h_fwd_mfma16w<PREC_BF16>, g, blk, lds, st, x, y, (int)T, cps, chunk_len, nchunks, m->mpw_bf, fa);
+            else
+                hipLaunchKernelGGL(b2h_fwd_mfma16w<PREC_F16>, g, blk, lds, st, x, y, (int)T, cps, chunk_len, nchunks, m->mpw_h, fa);
+        } else if (k == B2H_KERNEL_F32_MFMA) {
             const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_F32>::kRowBytes;
-            int rc = ensure_lds(m, 1, b2h_fwd_mfma_f32, lds);
-            if (rc) return rc;
             hipLaunchKernelGGL(b2h_fwd_mfma_f32, g, blk, lds, st, x, y, (int)T, cps, chunk_len, nchunks, m->mp32, fa);
         } else if (k == B2H_KERNEL_F16X3_MFMA) {
             const size_t lds = (size_t)kWavesPerBlock * 2 * kImg3; // hi + lo images = the fp32 image's bytes
-            int rc = ensure_lds(m, 8, b2h_fwd_mfma_f16x3, lds);
-            if (rc) return rc;
             hipLaunchKernelGGL(b2h_fwd_mfma_f16x3, g, blk, lds, st, x, y, (int)T, cps, chunk_len, nchunks, m->mp3, fa);
         } else {
             // persistent kernel: one 512-thread workgroup per CU
@@ -352,18 +423,13 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             const bool fused = fa.flags != 0;
             const bool bf = (k == B2H_KERNEL_BF16_MFMA);
             const void* wp = bf ? m->mbf16_all.p : m->mf16_all.p;
-            int rc = B2H_OK;
-#define B2H_LAUNCH16(PR, FU, SLOT)                                                                        \
-    do {                                                                                                  \
-        rc = ensure_lds(m, SLOT, b2h_fwd_mfma16<PR, FU>, kLds16);                                         \
-        if (rc) return rc;                                                                                \
-        hipLaunchKernelGGL((b2h_fwd_mfma16<PR, FU>), dim3(grid16), dim3(64 * kWaves16), kLds16, st, x, y, \
-                           (int)T, cps16, TT, nch, wp, m->pos_emb, fa);                                   \
-    } while (0)
-            if (bf && !fused) B2H_LAUNCH16(PREC_BF16, false, 4);
-            else if (bf) B2H_LAUNCH16(PREC_BF16, true, 5);
-            else if (!fused) B2H_LAUNCH16(PREC_F16, false, 6);
-            else B2H_LAUNCH16(PREC_F16, true, 7);
+#define B2H_LAUNCH16(PR, FU)                                                                          \
+    hipLaunchKernelGGL((b2h_fwd_mfma16<PR, FU>), dim3(grid16), dim3(64 * kWaves16), kLds16, st, x, y, \
+                       (int)T, cps16, TT, nch, wp, m->pos_emb, fa)
+            if (bf && !fused) B2H_LAUNCH16(PREC_BF16, false);
+            else if (bf) B2H_LAUNCH16(PREC_BF16, true);
+            else if (!fused) B2H_LAUNCH16(PREC_F16, false);
+            else B2H_LAUNCH16(PREC_F16, true);
 #undef B2H_LAUNCH16
         }
     }
@@ -384,7 +450,6 @@ struct TencBlob {
 struct b2h_tenc {
     int nlayers = 0, max_len = 0, device = 0;
     bool has_weights = false;
-    bool lds_attr = false;
     int kernel = B2H_TENC_F32;
     float w_absmax = 0.f; // largest |parameter| (NaN counts as inf): B2H_TENC_F16X3 needs < 65504
     DevBuf pe;
@@ -451,13 +516,6 @@ ChainStage stage_of(const b2h_tenc* m, const TencBlob& B, int type, float* out, 
 
 int launch_chain(b2h_tenc* m, ChainArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * kStageBlobMax * sizeof(float);
-    if (!m->lds_attr) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_tenc_chain<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_tenc_chain<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        m->lds_attr = true;
-    }
     const int64_t blocks = (a.n + 16 * kLinWaves - 1) / (16 * kLinWaves);
     if (m->kernel == B2H_TENC_F16X3)
         hipLaunchKernelGGL(b2h_tenc_chain<true>, dim3((unsigned)blocks), dim3(64 * kLinWaves), lds, st, a);
@@ -525,6 +583,11 @@ int b2h_tenc_load_weights(b2h_tenc* m, const float* const* tensors, int count, i
         else std::memcpy(h[i].data(), tensors[i], sizes[i] * 4);
     }
     HIP_TRY(hipDeviceSynchronize());
+    if (int rc0 = check_device(m->device)) return rc0;
+    // LDS caps are raised here, not in b2h_tenc_forward: the first forward is already capture-safe
+    constexpr int kChainLds = 2 * kStageBlobMax * (int)sizeof(float);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_tenc_chain<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_tenc_chain<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds));
     m->w_absmax = 0.f;
     for (int i = 1; i < count; ++i) m->w_absmax = absmax_of(h[i], m->w_absmax); // h[0] is the pe table (|pe| <= 1)
     int rc;
@@ -698,8 +761,10 @@ int b2h_load_weights(b2h_model* m, const float* w1, const float* b1, const float
         }
     }
     HIP_TRY(hipDeviceSynchronize()); // no launch may still read the old packed buffers
-    int rc = pack_all(m, hw);
+    int rc = check_device(m->device);
     if (rc) return rc;
+    if ((rc = set_conv_kernel_attributes())) return rc;
+    if ((rc = pack_all(m, hw))) return rc;
     m->has_weights = true;
     return B2H_OK;
 }
@@ -721,8 +786,13 @@ int b2h_target_transform(const float* body, const float* hand, float* hand_out, 
                          float factor, void* stream) {
     if (B < 0 || T < 0) return fail(B2H_ERR_SHAPE, "negative shape");
     if (B * T == 0) return B2H_OK;
-    if (!body || !hand || !hand_out) return fail(B2H_ERR_INVALID, "NULL pointer");
+    if (B > 0x7fffffff || T > (1 << 24)) return fail(B2H_ERR_SHAPE, "shape too large");
+    if (flags & ~3) return fail(B2H_ERR_INVALID, "unknown flag bits");
     if ((flags & 2) && !(factor > 0.f)) return fail(B2H_ERR_INVALID, "factor must be > 0");
+    int rc;
+    if ((rc = check_device_ptr(body, "body")) || (rc = check_device_ptr(hand, "hand")) ||
+        (rc = check_device_ptr(hand_out, "hand_out")))
+        return rc;
     const int64_t n = B * T * 21;
     const int64_t blocks = std::min<int64_t>((n + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(b2h_target_transform_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, body,
@@ -735,7 +805,11 @@ int b2h_masked_l1(const float* pred, const float* target, const int64_t* n_frame
                   float* per_seq, float* loss, void* stream) {
     if (B < 1 || T < 1) return fail(B2H_ERR_SHAPE, "masked L1 needs B >= 1 and T >= 1");
     if (B > 0x7fffffff || T > (1 << 24)) return fail(B2H_ERR_SHAPE, "shape too large");
-    if (!pred || !target || !per_seq || !loss) return fail(B2H_ERR_INVALID, "NULL pointer");
+    int rc;
+    if ((rc = check_device_ptr(pred, "pred")) || (rc = check_device_ptr(target, "target")) ||
+        (rc = check_device_ptr(per_seq, "per_seq")) || (rc = check_device_ptr(loss, "loss")) ||
+        (n_frames && (rc = check_device_ptr(n_frames, "n_frames"))))
+        return rc;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(b2h_masked_l1_seq_kernel, dim3((unsigned)B), dim3(256), 0, st, pred, target, n_frames, per_seq,
                        (int)T);
@@ -762,8 +836,8 @@ const char* b2h_kernel_name(const b2h_model* m, int kernel) {
     switch (resolve_kernel(m, kernel)) {
         case B2H_KERNEL_F32_VALU: return "b2h_fwd_f32_valu";
         case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma_f32";
-        case B2H_KERNEL_BF16_MFMA: return "b2h_fwd_mfma16<1, false>";
-        case B2H_KERNEL_F16_MFMA: return "b2h_fwd_mfma16<2, false>";
+        case B2H_KERNEL_BF16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<1>" : "b2h_fwd_mfma16<1, false>";
+        case B2H_KERNEL_F16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<2>" : "b2h_fwd_mfma16<2, false>";
         case B2H_KERNEL_F16X3_MFMA: return "b2h_fwd_mfma_f16x3";
         default: return "";
     }

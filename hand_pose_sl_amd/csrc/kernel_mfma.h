@@ -75,6 +75,47 @@ struct ChunkCtx {
     int64_t nvalid; // frames kept by the tail mask
 };
 
+// Buffer descriptor over [base, base + bytes): loads past the end return 0 and stores
+// past the end are dropped by the hardware range check, so one VGPR byte offset
+// (plus SGPR/immediate offsets) addresses everything and no lane predicate is needed.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, bytes, 0x00020000);
+}
+
+// Head epilogue of the wave-per-chunk kernels.  Lane (tcol, q) owns channels 16mt + 4q .. +3 of
+// frame t: 16 B at byte 168 (t - s) + 64 mt + 16 q of the chunk's output rows [s, e), stored with
+// buffer_store_dwordx4 (rows are 8-byte aligned only, which buffer stores allow); frames >= e fall
+// outside the descriptor and are dropped by the range check, channels 40, 41 are an 8-byte store.
+// Every offset that varies is in the VGPR offset (immediate soffset), so hipcc pads the store-data
+// write-after-read hazard itself (tests/test_isa_audit.py).
+struct HeadStore {
+    __amdgpu_buffer_rsrc_t rs;
+    int off, t0;
+    __device__ __forceinline__ void init(const ChunkCtx& cx, int lo) { // lo == cx.s for the head
+        rs = make_rsrc(cx.y + (int64_t)lo * kOutCh, (cx.e - lo) * (kOutCh * 4));
+        off = cx.tcol * (kOutCh * 4) + 16 * cx.q;
+        t0 = lo + cx.tcol;
+    }
+    __device__ __forceinline__ void store(const ChunkCtx& cx, const f32x4 (&acc)[3], int m) {
+        const bool dead = (int64_t)(t0 + 16 * m) >= cx.nvalid; // tail mask (utils.py:309-312)
+        const int vo = off + m * (16 * kOutCh * 4);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+            f32x4 v = acc[mt];
+            if (cx.fa.flags & kPostDenorm) v = v * cx.fa.factor;     // traintest.py:387-388
+            if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mt < 2 || cx.q < 2)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, vo + 64 * mt, 0, 0);
+            else if (cx.q == 2) // channels 40, 41 (elements passed BY VALUE: see kernel_mfma16.h)
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}, rs,
+                                                      vo + 64 * mt, 0, 0);
+        }
+    }
+};
+
 // ---- exact-fp32 layers (v_mfma_f32_16x16x4_f32) -------------------------------
 template <int L>
 __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp) {
@@ -99,6 +140,8 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
     }
     const int pin = 8 - 2 * L - cx.s;
     const int pout = pin - 2;
+    HeadStore hs;
+    if constexpr (L == 3) hs.init(cx, lo);
 
 #pragma unroll 1
     for (int m = 0; m < ntiles; ++m) {
@@ -138,22 +181,7 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
             for (int mt = 0; mt < 2; ++mt) // channels 8q + 4mt .. +3  ->  16-B chunk 2q + mt
                 *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(t + pout, 2 * cx.q + mt)) = o[mt];
         } else {
-            if (t < cx.e) {
-                float* yr = cx.y + (int64_t)t * kOutCh + 4 * cx.q;
-                const bool dead = (int64_t)t >= cx.nvalid;
-#pragma unroll
-                for (int mt = 0; mt < 3; ++mt) {
-                    f32x4 v = acc[mt];
-                    if (cx.fa.flags & kPostDenorm) v = v * cx.fa.factor;
-                    if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (mt < 2 || cx.q < 2) {
-                        *reinterpret_cast<float2*>(yr + 16 * mt) = float2{v[0], v[1]};
-                        *reinterpret_cast<float2*>(yr + 16 * mt + 2) = float2{v[2], v[3]};
-                    } else if (cx.q == 2) {
-                        *reinterpret_cast<float2*>(yr + 16 * mt) = float2{v[0], v[1]};
-                    }
-                }
-            }
+            hs.store(cx, acc, m);
         }
     }
     if constexpr (L < 3) {

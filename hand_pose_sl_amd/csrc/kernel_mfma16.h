@@ -85,16 +85,6 @@ __device__ __forceinline__ Geom16 geom16(int64_t chunk, int cps, int TT, int T) 
 struct InRegs { float4 v[kInRegs]; };   // next chunk's rows as loaded (fp32)
 struct InRegs16 { uint2 p[kInRegs]; };  // the same, cast to 4 x 16-bit
 
-// Buffer descriptor over [base, base + bytes): loads past the end return 0 and stores
-// past the end are dropped by the hardware range check, so one VGPR byte offset
-// (plus SGPR/immediate offsets) addresses everything and no lane predicate is needed.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, bytes, 0x00020000);
-}
-
 // Request a chunk's input rows: 20 x 16 B per lane, lane-contiguous (coalesced 1 KiB
 // per instruction).  bytes == 0 (nothing left to prefetch) issues no memory traffic.
 __device__ __forceinline__ void issue_loads16(InRegs& R, const float* base, int bytes, int lane) {

@@ -1,0 +1,206 @@
+// bf16/f16 matrix-core kernel for WIDE models: conv_channels in 33..64.
+//
+// Path: ConvModel.forward, HandPoseModels.py:40-64; `--conv-channels` is a free integer
+// (run.py:37, HandPoseModels.py:18,24-32).  Same mapping as the other wave-per-chunk kernels
+// (kernel_mfma.h: one wave owns one chunk of one sequence and carries it through all four layers,
+// weights in registers, in-place LDS image, no workgroup barrier) with twice the channel padding:
+//
+//   LDS image  : rows [time][64 ch] of 16-bit = 128 B, 16-B chunk c of physical row P stored at
+//                chunk c ^ (P & 7): conflict-free for the ds_read_b128 fragment reads at every row
+//                alignment and for the ds_write_b128 write-back (searched over all XOR swizzles
+//                with the lane groups of MI355X_MICROARCH.md; a 16-row tile step leaves it unchanged)
+//   layer l    : D[slot][time] += W_l[slot][(tap, pos)] . Act[(tap, pos)][time]; one tap = TWO
+//                16x16x32 k-steps (in-positions 0..31, 32..63; layer 1 has 24|25 inputs = one),
+//                4 M-tiles of out-channel slots (head: 3 = 42 -> 48).  All of a layer's weight
+//                fragments stay in registers: 4 x 5 x 2 x 4 = 160 VGPRs, which still leaves two
+//                waves per SIMD (hipcc: ~200 registers), so no second pass and no second image.
+//   slot map   : hidden out-channel (M-tile mt, row 4q+r) <-> channel 16q + 4mt + r, so a lane's 16
+//                results are the 16 consecutive channels of chunks 2q, 2q+1 of the next layer's
+//                row: two ds_write_b128 per lane and tile.
+//
+// Weights come from L2 once per layer and chunk (40 KB for a hidden layer at 64 channels); the
+// kernel is matrix-pipe-bound (130 MFMAs per 16 frames against 45 at <= 32 channels).
+#pragma once
+#include "kernel_mfma.h"
+#include "kernel_mfma16.h" // pack2, relu_bits
+
+namespace b2h {
+
+constexpr int kWideRowB = 128;                 // bytes per LDS row: 64 channels x 16 bit
+constexpr int kWideMT = 4;                     // M-tiles of a hidden layer (64 out-channel slots)
+constexpr int kImgW = kRows * kWideRowB;       // LDS bytes per wave (18 KB: 2 x 4 waves per CU)
+
+__host__ __device__ inline int wide_chan_of(int mt, int row) { return 16 * (row >> 2) + 4 * mt + (row & 3); }
+
+__device__ __forceinline__ int lds_offw(int P, int c) { return P * kWideRowB + ((c ^ (P & 7)) << 4); }
+
+// fragment counts / offsets of the packed weights: per layer [mt][tap][ks][lane] x 16 B
+__host__ __device__ constexpr int wide_mt(int L) { return L == 3 ? 3 : kWideMT; }
+__host__ __device__ constexpr int wide_ks(int L) { return L == 0 ? 1 : 2; }
+
+template <int PREC, int L>
+__device__ __forceinline__ void layer16w(const ChunkCtx& cx, const MfmaParams& mp) {
+    using P = Prec<PREC>;
+    using vec8 = typename P::vec8;
+    constexpr int MT = wide_mt(L), KS = wide_ks(L);
+    constexpr int h = 6 - 2 * L;
+    const int lo = max(cx.s - h, 0), hi = min(cx.e + h, cx.T);
+    const int ntiles = (hi - lo + 15) >> 4;
+
+    vec8 A[MT][kTaps][KS]; // in-positions 32ks + 8q + j of out-channel slot (lane & 15)
+    f32x4 bias[MT];
+    {
+        const vec8* wp = reinterpret_cast<const vec8*>(mp.w[L]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int s = 0; s < kTaps; ++s)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) A[mt][s][ks] = wp[((mt * kTaps + s) * KS + ks) * 64 + cx.lane];
+        const f32x4* bp = reinterpret_cast<const f32x4*>(mp.bias[L]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) bias[mt] = bp[mt * 4 + cx.q];
+    }
+    const int pin = 8 - 2 * L - cx.s;
+    const int pout = pin - 2;
+    // swizzled byte offsets of this lane's tap rows and of its write-back row in tile 0; a tile step
+    // is 16 rows = 2048 B and leaves the swizzle term (P & 7) unchanged
+    // (chunk 4 + q of a row = chunk q's offset ^ 64, chunk 2q + 1 = chunk 2q's ^ 16: one register per tap)
+    int roff[kTaps];
+#pragma unroll
+    for (int s = 0; s < kTaps; ++s) roff[s] = lds_offw(lo + cx.tcol + s - kPad + pin, cx.q);
+    const int woff = lds_offw(lo + cx.tcol + pout, 2 * cx.q);
+    HeadStore hs;
+    if constexpr (L == 3) hs.init(cx, lo);
+
+#pragma unroll 1
+    for (int m = 0; m < ntiles; ++m) {
+        const int tau = lo + 16 * m;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = bias[mt];
+#pragma unroll
+        for (int s = 0; s < kTaps; ++s)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const vec8 b = *reinterpret_cast<const vec8*>(cx.lds + ((roff[s] + m * (16 * kWideRowB)) ^ (64 * ks)));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = P::mfma(A[mt][s][ks], b, acc[mt]);
+            }
+        if constexpr (L < 3) {
+            float v[16]; // channels 16q + 4mt + r = slot 4mt + r of this lane's two chunks
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * mt + r] = relu_bits(acc[mt][r]);
+            if (tau + 16 > cx.T) { // only the tile that crosses the sequence end: frames >= T are padding
+                const bool inside = tau + cx.tcol < cx.T;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = inside ? v[j] : 0.f;
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const uint4 o = {pack2<PREC>(v[8 * hh], v[8 * hh + 1]), pack2<PREC>(v[8 * hh + 2], v[8 * hh + 3]),
+                                 pack2<PREC>(v[8 * hh + 4], v[8 * hh + 5]), pack2<PREC>(v[8 * hh + 6], v[8 * hh + 7])};
+                *reinterpret_cast<uint4*>(cx.lds + ((woff + m * (16 * kWideRowB)) ^ (16 * hh))) = o;
+            }
+        } else {
+            hs.store(cx, acc, m);
+        }
+    }
+    if constexpr (L < 3) {
+        if (hi == cx.T) { // rows T, T+1 of the next layer's input: zero unless a tile covered them
+            const int covered = lo + 16 * ntiles;
+            const int t = cx.T + (cx.lane >> 3);
+            if (cx.lane < 16 && t >= covered)
+                *reinterpret_cast<uint4*>(cx.lds + lds_offw(t + pout, cx.lane & 7)) = uint4{0u, 0u, 0u, 0u};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ---- input staging: (T,24) fp32 rows -> 16-bit image of the layer-1 input (chunks 0..3) ----------
+template <int PREC>
+__device__ __forceinline__ void stage_input16w(const ChunkCtx& cx, const float* __restrict__ xs, int pos_emb) {
+    const int in_lo = max(cx.s - kHalo, 0), in_hi = min(cx.e + kHalo, cx.T);
+    const int pin = 8 - cx.s; // P(t,0) = t + pin
+    const int nf4 = (in_hi - in_lo) * (kInCh / 4);
+    const float4* src = reinterpret_cast<const float4*>(xs + (int64_t)in_lo * kInCh);
+    for (int i0 = cx.lane; i0 < nf4; i0 += 64 * 8) { // 8 loads in flight per lane
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u;
+            v[u] = (i < nf4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u;
+            if (i >= nf4) continue;
+            const int rr = i / 6, c4 = i - rr * 6;
+            const int t = in_lo + rr;
+            float4 w = v[u];
+            if (cx.fa.flags & kPreChest) { // body -= body[:,1]  (steps/utils.py:203-210)
+                const float2 ch = *reinterpret_cast<const float2*>(xs + (int64_t)t * kInCh + 2);
+                w.x -= ch.x; w.y -= ch.y; w.z -= ch.x; w.w -= ch.y;
+            }
+            if (cx.fa.flags & kPreNorm) { // body / factor     (steps/utils.py:180-190)
+                w.x = w.x / cx.fa.factor; w.y = w.y / cx.fa.factor;
+                w.z = w.z / cx.fa.factor; w.w = w.w / cx.fa.factor;
+            }
+            // channels 4c4 .. 4c4+3: half (c4 & 1) of 16-B chunk c4 >> 1
+            *reinterpret_cast<uint2*>(cx.lds + lds_offw(t + pin, c4 >> 1) + (c4 & 1) * 8) =
+                uint2{pack2<PREC>(w.x, w.y), pack2<PREC>(w.z, w.w)};
+        }
+    }
+    // in-positions 24..31 = chunk 3 (pos_emb: position 24 = t/100, HandPoseModels.py:71-75; the layer-1
+    // weights are packed with the position channel moved to slot 24).  Layer 1 reads chunks 0..3 only.
+    const int nrows = in_hi - in_lo;
+    for (int r = cx.lane; r < nrows; r += 64) {
+        const int t = in_lo + r;
+        uint4 z = {0u, 0u, 0u, 0u};
+        if (pos_emb) z.x = pack2<PREC>((float)t / 100.0f, 0.f);
+        *reinterpret_cast<uint4*>(cx.lds + lds_offw(t + pin, 3)) = z;
+    }
+    // zero rows (all 8 chunks: later layers read them whole): t in [-8,0) at the sequence start (every
+    // layer's low padding) and t = T, T+1 at the sequence end
+    if (cx.s == 0) *reinterpret_cast<uint4*>(cx.lds + lds_offw(cx.lane >> 3, cx.lane & 7)) = uint4{0u, 0u, 0u, 0u};
+    if (in_hi == cx.T && cx.lane < 16)
+        *reinterpret_cast<uint4*>(cx.lds + lds_offw(cx.T + (cx.lane >> 3) + pin, cx.lane & 7)) = uint4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One wave per (sequence, chunk); no workgroup barrier anywhere.  18 KB of LDS per wave: two 4-wave
+// workgroups per CU = 2 waves per SIMD, each within 256 VGPRs.
+template <int PREC>
+__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma16w(
+    const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq, int chunk_len,
+    int64_t nchunks, MfmaParams mp, FusedArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) char smem_mfma16w[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (chunk >= nchunks) return;
+
+    ChunkCtx cx;
+    cx.lds = smem_mfma16w + (size_t)wave * kImgW;
+    cx.lane = threadIdx.x & 63;
+    cx.tcol = cx.lane & 15;
+    cx.q = cx.lane >> 4;
+    cx.T = T;
+    cx.seq = chunk / chunks_per_seq;
+    const int c = (int)(chunk - cx.seq * chunks_per_seq);
+    cx.s = c * chunk_len; // <= kChunk frames (the LDS image's capacity); shorter when the batch is small
+    cx.e = min(cx.s + chunk_len, T);
+    cx.y = y + cx.seq * (int64_t)T * kOutCh;
+    cx.fa = fa;
+    cx.nvalid = T;
+    if ((fa.flags & kPostMask) && fa.n_frames) cx.nvalid = fa.n_frames[cx.seq];
+    stage_input16w<PREC>(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
+    layer16w<PREC, 0>(cx, mp); layer16w<PREC, 1>(cx, mp); layer16w<PREC, 2>(cx, mp); layer16w<PREC, 3>(cx, mp);
+}
+
+} // namespace b2h

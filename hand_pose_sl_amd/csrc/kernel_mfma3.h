@@ -82,6 +82,8 @@ __device__ __forceinline__ void layer3(const ChunkCtx& cx, const MfmaParams& mp)
 #pragma unroll
     for (int s = 0; s < kTaps; ++s) roff[s] = lds_off<64>(lo + cx.tcol + s - kPad + pin, cx.q);
     int woff = lds_off<64>(lo + cx.tcol + pout, cx.q);
+    HeadStore hs;
+    if constexpr (L == 3) hs.init(cx, lo);
 
 #pragma unroll 1
     for (int m = 0; m < ntiles; ++m) {
@@ -119,22 +121,7 @@ __device__ __forceinline__ void layer3(const ChunkCtx& cx, const MfmaParams& mp)
             *reinterpret_cast<f16x8*>(img_l + woff) = ol;
             woff += 16 * 64;
         } else {
-            if (t < cx.e) {
-                float* yr = cx.y + (int64_t)t * kOutCh + 4 * cx.q;
-                const bool dead = (int64_t)t >= cx.nvalid;
-#pragma unroll
-                for (int mt = 0; mt < 3; ++mt) {
-                    f32x4 v = acc[mt];
-                    if (cx.fa.flags & kPostDenorm) v = v * cx.fa.factor;
-                    if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (mt < 2 || cx.q < 2) {
-                        *reinterpret_cast<float2*>(yr + 16 * mt) = float2{v[0], v[1]};
-                        *reinterpret_cast<float2*>(yr + 16 * mt + 2) = float2{v[2], v[3]};
-                    } else if (cx.q == 2) {
-                        *reinterpret_cast<float2*>(yr + 16 * mt) = float2{v[0], v[1]};
-                    }
-                }
-            }
+            hs.store(cx, acc, m);
         }
     }
     B2H_STAMP3(cx, 3 + 2 * L); // tiles done

@@ -43,10 +43,12 @@ typedef enum b2h_status {
 typedef enum b2h_kernel {
     B2H_KERNEL_AUTO = 0,      /* F32_MFMA when it supports the width, else F32_VALU   */
     B2H_KERNEL_F32_VALU = 1,  /* fp32 FMA on the vector ALU; any conv_channels <= 64   */
-    B2H_KERNEL_F32_MFMA = 2,  /* exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32)      */
-    B2H_KERNEL_BF16_MFMA = 3, /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
-    B2H_KERNEL_F16_MFMA = 4,  /* fp16 operands, fp32 accumulate (v_mfma_f32_16x16x32_f16)  */
-    B2H_KERNEL_F16X3_MFMA = 5 /* fp32-grade: every operand split into f16 hi + lo, three f16 MFMAs per
+    B2H_KERNEL_F32_MFMA = 2,  /* exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32); conv_channels <= 32 */
+    B2H_KERNEL_BF16_MFMA = 3, /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16); any
+                                 conv_channels <= 64 (33..64: the wide kernel, two k-steps per tap) */
+    B2H_KERNEL_F16_MFMA = 4,  /* fp16 operands, fp32 accumulate (v_mfma_f32_16x16x32_f16); <= 64 likewise */
+    B2H_KERNEL_F16X3_MFMA = 5 /* conv_channels <= 32.
+                                 fp32-grade: every operand split into f16 hi + lo, three f16 MFMAs per
                                  product (hi.hi + hi.lo + lo.hi), fp32 accumulate; needs |x| < 65504:
                                  a model with a weight outside that range is refused
                                  (B2H_ERR_UNSUPPORTED), an activation beyond it becomes inf / NaN */

@@ -41,7 +41,8 @@ def _model(rec, prec, dev):
 
 
 def _supported(rec, prec):
-    return rec["C"] <= 32 or prec == "f32_valu"
+    """conv_channels 33..64: the 16-bit matrix-core kernels (kernel_mfma16w.h) and the fp32 VALU kernel."""
+    return rec["C"] <= 32 or prec in ("f32_valu", "bf16", "f16")
 
 
 def _tol(rec, prec):
@@ -147,6 +148,45 @@ def test_config4_stream_sharded_equals_one_launch(prec, cuda_device):
     assert np.abs(y[idx].cpu().numpy() - ref).max() <= TOL[prec]
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16", "f32_valu"])
+@pytest.mark.parametrize("C", [33, 40, 47, 48, 49, 56, 63, 64])
+def test_wide_models_vs_oracle(C, prec, cuda_device):
+    """conv_channels is a free integer in the reference (run.py:37, HandPoseModels.py:24-32).  Widths
+    33..64 run on the wide 16-bit matrix-core kernel (two 32-channel k-steps per tap, four M-tiles);
+    checked against the oracle (reference bars) and the oracle's operand-rounding model on lengths
+    around the tile and chunk edges, with pos_emb (T = 100), small and large batches (different
+    chunkings must agree bit for bit), the fused transforms and batch independence."""
+    torch.manual_seed(1000 + C)
+    for pos_emb, lengths in ((False, [1, 5, 16, 17, 50, 111, 112, 113, 200, 225, 337]), (True, [100])):
+        m = hps.ConvModel(C, "ReLU", pos_emb, precision=prec).to(cuda_device).eval()
+        state = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        assert m.kernel_name() == {"bf16": "b2h_fwd_mfma16w<1>", "f16": "b2h_fwd_mfma16w<2>", "f32_valu": "b2h_fwd_f32_valu"}[prec]
+        g = torch.Generator().manual_seed(C)
+        for T in lengths:
+            x = torch.rand((4, T, 12, 2), generator=g) - 0.5
+            with torch.no_grad():
+                y = m(x.to(cuda_device))
+                big = m(torch.cat([x, torch.rand((1200, T, 12, 2), generator=g) - 0.5]).to(cuda_device))
+            assert torch.equal(big[:4], y), (C, prec, T)                     # other chunking, other neighbours
+            y = y.cpu().numpy()
+            ref = oracle.forward_from_state(x.numpy(), state, pos_emb=pos_emb)
+            assert np.abs(y - ref).max() <= TOL[prec], (C, prec, T, np.abs(y - ref).max())
+            if prec in ORACLE_MODE:
+                ym = oracle.forward_from_state(x.numpy(), state, pos_emb=pos_emb, mode=ORACLE_MODE[prec])
+                assert np.abs(y - ym).max() <= TOL_MODEL[prec], (C, prec, T)
+        if not pos_emb:   # fused pixel pipeline with a ragged tail mask (SURVEY.md 8f N1)
+            rng = np.random.default_rng(C)
+            body = (rng.random((5, 130, 12, 2), dtype=np.float32)) * np.array([1280.0, 720.0], np.float32)
+            nf = np.array([130, 1, 64, 129, 77])
+            with torch.no_grad():
+                yf = m.forward_fused(torch.from_numpy(body).to(cuda_device), n_frames=nf, mask_tail=True).cpu().numpy()
+            inp, _ = oracle.preprocess(body, None)
+            ref = oracle.postprocess(oracle.forward_from_state(inp, state), 1280.0, nf)
+            assert np.abs(yf - ref).max() <= 2 * TOL[prec] * 1280
+            for b, n in enumerate(nf):
+                assert not yf[b, n:].any()
+
+
 def test_module_surface(cuda_device):
     """The call surface steps/traintest.py uses: host tensor in (body_kp is never moved,
     :354-358), result on the model's device, caller mutates it in place (:387-388)."""
@@ -229,8 +269,8 @@ def test_hip_graph_capture_and_replay(prec, cuda_device):
     g = torch.Generator().manual_seed(21)
     x_static = (torch.rand((32, 200, 12, 2), generator=g) - 0.5).to(cuda_device)
     with torch.no_grad():
-        m(x_static)                                   # first launch sets the LDS attribute
-        torch.cuda.synchronize()
+        m._ensure_handle()                            # weights packed (and LDS caps raised) at load time:
+        torch.cuda.synchronize()                      # the FIRST forward is already capture-safe
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             y_static = m(x_static)
@@ -259,6 +299,19 @@ def test_c_abi_argument_checks(cuda_device):
     assert b"overlap" in lib.b2h_last_error()
     assert lib.b2h_forward(m._handle, vp(x.data_ptr()), vp(y.data_ptr()), 1, 0, 3, None) == _lib.ERR_SHAPE
     assert lib.b2h_forward(m._handle, vp(x.data_ptr()), vp(y.data_ptr()), 1, 200, 9, None) == _lib.ERR_UNSUPPORTED
+    # the model-free entry points check their pointers too: NULL and host memory are refused
+    d = torch.zeros(2 * 5 * 42, dtype=torch.float32, device=cuda_device)
+    b = torch.zeros(2 * 5 * 24, dtype=torch.float32, device=cuda_device)
+    host = torch.zeros(2 * 5 * 42, dtype=torch.float32)
+    out2 = torch.zeros(3, dtype=torch.float32, device=cuda_device)
+    assert lib.b2h_masked_l1(vp(d.data_ptr()), vp(d.data_ptr()), None, 2, 5, vp(out2.data_ptr()), vp(out2.data_ptr() + 8), None) == _lib.OK
+    assert lib.b2h_masked_l1(vp(host.data_ptr()), vp(d.data_ptr()), None, 2, 5, vp(out2.data_ptr()), vp(out2.data_ptr() + 8), None) == _lib.ERR_INVALID
+    assert b"pred" in lib.b2h_last_error()
+    assert lib.b2h_masked_l1(vp(d.data_ptr()), None, None, 2, 5, vp(out2.data_ptr()), vp(out2.data_ptr() + 8), None) == _lib.ERR_INVALID
+    assert b"NULL" in lib.b2h_last_error()
+    assert lib.b2h_target_transform(vp(b.data_ptr()), vp(d.data_ptr()), vp(d.data_ptr()), 2, 5, 3, 1280.0, None) == _lib.OK
+    assert lib.b2h_target_transform(vp(b.data_ptr()), vp(host.data_ptr()), vp(d.data_ptr()), 2, 5, 3, 1280.0, None) == _lib.ERR_INVALID
+    assert lib.b2h_target_transform(vp(b.data_ptr()), vp(d.data_ptr()), vp(d.data_ptr()), 2, 5, 8, 1280.0, None) == _lib.ERR_INVALID
     torch.cuda.synchronize()
 
 
