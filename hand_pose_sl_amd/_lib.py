@@ -47,6 +47,8 @@ SYMBOLS = {
     "b2h_tenc_load_weights": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int]),
     "b2h_tenc_workspace_bytes": (ctypes.c_size_t, [_vp, ctypes.c_int64, ctypes.c_int64]),
     "b2h_tenc_forward": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_size_t, _vp]),
+    "b2h_tenc_forward_fused": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
+                                              _vp, _vp, ctypes.c_size_t, _vp]),
     "b2h_model_info": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                       ctypes.POINTER(ctypes.c_int)]),
     "b2h_kernel_supported": (ctypes.c_int, [_vp, ctypes.c_int]),

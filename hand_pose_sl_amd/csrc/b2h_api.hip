@@ -614,8 +614,11 @@ size_t b2h_tenc_workspace_bytes(const b2h_tenc* m, int64_t B, int64_t T) {
     return (size_t)B * T * (5 * kTencD) * sizeof(float); // residual stream XA, attention output OC (128 each) + QKV (384)
 }
 
-int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T, void* workspace,
-                     size_t workspace_bytes, void* stream) {
+} // extern "C"
+
+namespace {
+int tenc_launch(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T, const FusedArgs& fa, void* workspace,
+                size_t workspace_bytes, void* stream) {
     if (!m) return fail(B2H_ERR_INVALID, "model is NULL");
     if (!m->has_weights) return fail(B2H_ERR_NO_WEIGHTS, "b2h_tenc_forward before b2h_tenc_load_weights");
     if (B < 0 || T < 1) return fail(B2H_ERR_SHAPE, "expected B >= 0 and T >= 1");
@@ -643,6 +646,7 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
         ChainArgs a{};
         a.x = x; a.ldx = kInCh; a.kgroups0 = 2; a.kvalid = kInCh; a.pe = (const float*)m->pe.p; a.T = (int)T;
         a.res = nullptr; a.n = n; a.nstages = 4;
+        a.flags = fa.flags & (kPreChest | kPreNorm); a.factor = fa.factor; a.Tseq = (int)T;
         a.st[0] = stage_of(m, m->in_proj, ST_SET, XA, kTencD);
         a.st[1] = stage_of(m, m->layers[0].q, ST_STORE, QKV, 3 * kTencD);
         a.st[2] = stage_of(m, m->layers[0].k, ST_STORE, QKV + kTencD, 3 * kTencD);
@@ -683,11 +687,31 @@ int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T
             a.st[2] = stage_of(m, L.ff2, ST_RESLN_REG, nullptr, kTencD);
             a.st[3] = stage_of(m, m->out_proj, ST_STORE, y, kOutCh);
             a.nstages = 4;
+            a.flags = fa.flags & (kPostDenorm | kPostMask); a.factor = fa.factor; a.n_frames = fa.n_frames;
         }
+        a.Tseq = (int)T;
         if ((rc = launch_chain(m, a, st))) return rc;
     }
     HIP_TRY(hipGetLastError());
     return B2H_OK;
+}
+} // namespace
+
+extern "C" {
+
+int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    FusedArgs fa{0, 1.0f, nullptr};
+    return tenc_launch(m, x, y, B, T, fa, workspace, workspace_bytes, stream);
+}
+
+int b2h_tenc_forward_fused(b2h_tenc* m, const float* body, float* y, int64_t B, int64_t T, int flags, float factor,
+                           const int64_t* n_frames, void* workspace, size_t workspace_bytes, void* stream) {
+    if (flags & ~(kPreChest | kPreNorm | kPostDenorm | kPostMask)) return fail(B2H_ERR_INVALID, "unknown flag bits");
+    if ((flags & (kPreNorm | kPostDenorm)) && !(factor > 0.f)) return fail(B2H_ERR_INVALID, "factor must be > 0");
+    if ((flags & kPostMask) && !n_frames) return fail(B2H_ERR_INVALID, "B2H_POST_MASK_TAIL needs n_frames");
+    FusedArgs fa{flags, factor, n_frames};
+    return tenc_launch(m, body, y, B, T, fa, workspace, workspace_bytes, stream);
 }
 
 } // extern "C"
@@ -870,14 +894,4 @@ int b2h_stream_sync(void* stream) {
 
 } // extern "C"
 
-#if B2H_ABLATE & 16384
-extern "C" int b2h_debug_chain_stamps(unsigned long long* out) { // development only, not in b2h.h
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(b2h::g_chain_dbg), 8 * 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
-}
-#endif
-
-#if B2H_ABLATE & 32768
-extern "C" int b2h_debug_conv3_stamps(unsigned long long* out) { // development only, not in b2h.h
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(b2h::g_conv3_dbg), 4 * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
-}
-#endif
+#include "dev/b2h_dev_exports.h" // empty unless a B2H_ABLATE stamp build

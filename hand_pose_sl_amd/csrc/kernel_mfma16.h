@@ -26,12 +26,6 @@
 #include "b2h_common.h"
 #include "kernel_mfma.h"
 
-// Development only: -DB2H_ABLATE=<bits> builds a timing-only variant with parts of the
-// kernel removed (1 no MFMA, 2 no global stores, 4 no global loads, 8 no fragment
-// reads, 16 no write-back, 32 lane-linear output stores).  Results are wrong by construction; never shipped.
-#ifndef B2H_ABLATE
-#define B2H_ABLATE 0
-#endif
 
 namespace b2h {
 
@@ -91,7 +85,6 @@ __device__ __forceinline__ void issue_loads16(InRegs& R, const float* base, int 
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
 #pragma unroll
     for (int j = 0; j < kInRegs; ++j) {
-        if (B2H_ABLATE & 4) { R.v[j] = make_float4(0.25f, 0.5f, -0.25f, 0.125f); continue; }
         const i32x4 r = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0));
         R.v[j] = __builtin_bit_cast(float4, r);
     }
@@ -255,7 +248,6 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
         for (int s = 0; s < kTaps; ++s)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                if (B2H_ABLATE & 1) { acc[mt][0] += (float)Bf[s][0]; continue; }
                 acc[mt] = P::mfma(A[mt][s], Bf[s], acc[mt]);
             }
     };
@@ -275,11 +267,9 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
             }
             uint4 o = {pack2<PREC>(v[0], v[1]), pack2<PREC>(v[2], v[3]), pack2<PREC>(v[4], v[5]),
                        pack2<PREC>(v[6], v[7])};
-            if (!(B2H_ABLATE & 16) || T < 0) *reinterpret_cast<uint4*>(lds + wr + m * 1024) = o;
-            else asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+            *reinterpret_cast<uint4*>(lds + wr + m * 1024) = o;
         } else {
-            if ((B2H_ABLATE & 2) && T > 0) { asm volatile("" ::"v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0])); }
-            else {
+            {
                 // lane (tcol,q) owns channels 16mt + 4q .. +3 of frame tau + tcol: 16 B at
                 // row offset 168 (t - s) + 64 mt + 16 q; frames >= e fall outside the descriptor
                 const bool dead = FUSED && (tau + tcol >= nvalid); // tail mask (per lane)
@@ -291,10 +281,6 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
                         if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                     const int so = m * (16 * kOutCh * 4) + mt * 64;
-                    if (B2H_ABLATE & 32) { // timing probe: same bytes, lane-linear (perfectly coalesced, wrong layout)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, lane * 16, (m * 3 + mt) * 1024, 0);
-                        continue;
-                    }
                     if constexpr (FUSED) __builtin_amdgcn_sched_barrier(0); // store + its wait states stay adjacent (below)
                     if (mt < 2 || q < 2)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff, so, 0);
@@ -327,7 +313,6 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
     auto fetch = [&](vec8 (&Bf)[kTaps], int m) {
 #pragma unroll
         for (int s = 0; s < kTaps; ++s) {
-            if ((B2H_ABLATE & 8) && T > 0) { Bf[s] = A[0][s]; continue; }
             Bf[s] = *reinterpret_cast<const vec8*>(lds + rd[s] + m * 1024);
         }
     };

@@ -18,20 +18,12 @@
 #pragma once
 #include "kernel_mfma.h"
 #include "kernel_mfma16.h" // relu_bits
+#include "dev/b2h_dev.h"  // B2H_STAMP3: empty in the shipped build
 
 namespace b2h {
 
 constexpr int kImg3 = kRows * 64; // bytes of one image (hi or lo) of a wave
 
-#if B2H_ABLATE & 32768 // development: s_memtime stamps of one wave's phases (tools/conv3_stamps.py)
-__device__ unsigned long long g_conv3_dbg[4 * 16];
-#define B2H_STAMP3(cx, k)                                                                                   \
-    do {                                                                                                    \
-        if (blockIdx.x == gridDim.x / 2 && (cx).lane == 0) g_conv3_dbg[(threadIdx.x >> 6) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define B2H_STAMP3(cx, k) do { } while (0)
-#endif
 
 // hi = f16(v) packed two per instruction, residual v - hi as one mixed-precision FMA per value
 // (v_fma_mix_f32 reads the f16 half directly), lo = f16(residual) packed: 16 VALU for 8 values
@@ -65,8 +57,8 @@ __device__ __forceinline__ void layer3(const ChunkCtx& cx, const MfmaParams& mp)
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int s = 0; s < kTaps; ++s) {
-                Ah[mt][s] = wp[((mt * kTaps + s) * 2 + 0) * 64 + cx.lane];
-                Al[mt][s] = wp[((mt * kTaps + s) * 2 + 1) * 64 + cx.lane];
+                Ah[mt][s] = wp[((B2H_ABLATE & 64) ? 0 : ((mt * kTaps + s) * 2 + 0) * 64) + cx.lane];
+                Al[mt][s] = wp[((B2H_ABLATE & 64) ? 64 : ((mt * kTaps + s) * 2 + 1) * 64) + cx.lane];
             }
         const f32x4* bp = reinterpret_cast<const f32x4*>(mp.bias[L]);
 #pragma unroll
@@ -152,7 +144,7 @@ __device__ __forceinline__ void stage_input3(const ChunkCtx& cx, const float* __
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = i0 + 64 * u;
-            v[u] = (i < nf4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[u] = (i < nf4 && !(B2H_ABLATE & 128)) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {

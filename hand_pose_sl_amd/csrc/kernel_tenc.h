@@ -26,7 +26,8 @@
 #pragma once
 #include "b2h_common.h"
 #include "kernel_mfma.h"   // f32x4
-#include "kernel_mfma16.h" // make_rsrc, u32x4
+#include "kernel_mfma16.h" // pack helpers
+#include "dev/b2h_dev.h"   // B2H_ABLATE / B2H_STAMP hooks: constant-false / empty in the shipped build
 
 namespace b2h {
 
@@ -287,12 +288,6 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_h3(const float* __restr
 // in LDS: stage s+1's blob is requested from L2 before stage s's MFMAs and written to the other
 // buffer after them; one barrier per stage.
 enum { ST_SET = 0, ST_RELU = 1, ST_RESLN_GLOBAL = 2, ST_RESLN_REG = 3, ST_STORE = 4 };
-// Development only (tools/ablate_tenc.sh): timing builds of the chain kernel with parts removed
-// -- results are wrong.  256 no LayerNorm math, 1024 no blob staging, 2048 no per-stage
-// barrier, 4096 no stores, 8192 no MFMA, 16384 phase time stamps (tools/chain_stamps.py).
-#ifndef B2H_ABLATE
-#define B2H_ABLATE 0
-#endif
 constexpr int kChainMaxStages = 8;
 constexpr int kStageParams = 3 * kTencD;                                   // bias, gamma, beta
 constexpr int kStageBlobMax = kLinChunkMT * 8 * 64 * 4 + kStageParams;    // floats: 16384 + 384
@@ -311,6 +306,16 @@ struct ChainArgs {
     const float* res;    // residual rows (N, 128) for ST_RESLN_GLOBAL
     int64_t n;
     int nstages;
+    // item transforms fused around the model (b2h_tenc_forward_fused; same flags as FusedArgs):
+    //   front launch: kPreChest x -= x[:, chest] and kPreNorm x /= factor, BEFORE the positional
+    //                 encoding is added (the reference transforms the item, then the model adds pe:
+    //                 steps/utils.py:180-210, HandPoseModels.py:167);
+    //   last launch : kPostDenorm y *= factor (traintest.py:270-271) and kPostMask
+    //                 y[seq, n_frames[seq]:] = 0 (utils.py:309-312) in the 42-wide output store.
+    int flags;
+    float factor;
+    const int64_t* n_frames; // (B) for kPostMask
+    int Tseq;                // frames per sequence (the launch's own `T` is 1 behind the front)
     ChainStage st[kChainMaxStages];
 };
 
@@ -387,17 +392,6 @@ __device__ __forceinline__ f32x4 chain_ld(__amdgpu_buffer_rsrc_t rs, uint32_t of
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
 }
 
-#if B2H_ABLATE & 16384 // development: time stamps of one workgroup's phases (tools/chain_stamps.py)
-__device__ unsigned long long g_chain_dbg[8 * 64];
-#define B2H_STAMP()                                                                                        \
-    do {                                                                                                   \
-        if (blockIdx.x == gridDim.x / 2 && lane == 0 && a.nstages == 6 && nstamp < 64)                     \
-            g_chain_dbg[wave * 64 + nstamp] = __builtin_amdgcn_s_memtime();                                \
-        ++nstamp;                                                                                          \
-    } while (0)
-#else
-#define B2H_STAMP() do { } while (0)
-#endif
 
 template <bool H3> // false: fp32 operands (v_mfma_f32_16x16x4_f32); true: 3 x f16 split
 __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a) {
@@ -439,14 +433,33 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
         const __amdgpu_buffer_rsrc_t prs = make_rsrc(a.pe, a.pe ? a.T * a.kvalid * 4 : 0);
         const __amdgpu_buffer_rsrc_t rrs = make_rsrc(a.res ? a.res + n0 * kTencD : nullptr, a.res ? rows * kTencD * 4 : 0);
         const uint32_t pos = (uint32_t)((n0 + fr) % (a.T > 0 ? a.T : 1));
+        const int pre = __builtin_amdgcn_readfirstlane(a.flags) & (kPreChest | kPreNorm);
+        f32x4 chest = {0.f, 0.f, 0.f, 0.f};
+        if (pre & kPreChest) { // joint 1 = channels 2, 3 of the frame's own row: (x, y, x, y) per float4
+            const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)((uint32_t)(fr * a.ldx + 2) * 4u), 0, 0);
+            const float cx_ = __uint_as_float(c[0]), cy_ = __uint_as_float(c[1]);
+            chest = f32x4{cx_, cy_, cx_, cy_};
+        }
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int k0 = 16 * g + 4 * q;
             const bool have = g < a.kgroups0 && k0 < a.kvalid;
             cur[g] = chain_ld(xrs, have ? (uint32_t)(fr * a.ldx + k0) * 4u : kOob);
+            if (pre) { // wave-uniform; lanes without data hold zeros and stay zero
+                if (have) cur[g] -= chest;
+                if (pre & kPreNorm) cur[g] = cur[g] / a.factor; // true division, like the reference
+            }
             cur[g] += chain_ld(prs, have ? (pos * (uint32_t)a.kvalid + k0) * 4u : kOob);
             resid[g] = chain_ld(rrs, (uint32_t)(fr * kTencD + k0) * 4u);
         }
+    }
+    // output-side transforms of the 42-wide head (last launch only)
+    const int post = __builtin_amdgcn_readfirstlane(a.flags) & (kPostDenorm | kPostMask);
+    const float omul = (post & kPostDenorm) ? a.factor : 1.0f;
+    bool odead = false;
+    if ((post & kPostMask) && a.n_frames && fr < rows) {
+        const int64_t nn = n0 + fr;
+        odead = (nn % a.Tseq) >= a.n_frames[nn / a.Tseq];
     }
     f16x8 bh[4], bl[4]; // H3: the GEMM operand, split from `cur`
     if constexpr (H3) chain_split(cur, bh, bl);
@@ -536,9 +549,14 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
             const bool on = st.out != nullptr && !(B2H_ABLATE & 4096);
             const __amdgpu_buffer_rsrc_t ors = make_rsrc(on ? st.out + n0 * st.ldo : nullptr, on ? rows * st.ldo * 4 : 0);
             const bool raw = st.type == ST_STORE;
+            const bool head = post && raw && st.nout == kOutCh; // wave-uniform
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const f32x4 v = raw ? acc[m] : cur[m];
+                f32x4 v = raw ? acc[m] : cur[m];
+                if (head) {
+                    v = v * omul;                       // x factor, or x 1.0f (exact)
+                    if (odead) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
                 const int o0 = 16 * m + 4 * q;
                 const uint32_t off = (uint32_t)(fr * st.ldo + o0) * 4u;
                 const bool whole = m < st.mtiles && o0 + 3 < st.nout;

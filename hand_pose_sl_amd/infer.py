@@ -9,8 +9,9 @@ The working equivalent of the reference's `infer_utterance.py` (:52-111) + `step
         [--precision fp32]
 
 With `--model Conv` (default) transforms, model and de-normalisation run as ONE fused kernel
-(`ConvModel.forward_fused`); with `--model TransformerEnc` (infer_utterance.py:99-101) the
-item transforms run as device elementwise ops around the transformer kernels.
+(`ConvModel.forward_fused`); with `--model TransformerEnc` (infer_utterance.py:99-101) the item
+transforms run inside the transformer path's own first and last kernel
+(`TransformerEnc.forward_fused`).  No torch elementwise kernel runs on either path.
 Several utterances (sub-folders) are batched into one launch.
 """
 import argparse
@@ -32,19 +33,9 @@ def predict_utterances(model, utterances, max_frames=200, dif_encoding=False, no
     items = [openpose.load_utterance(u, max_frames) for u in utterances]
     body = torch.from_numpy(np.stack([it["body_kp"] for it in items]))
     dev = next(model.parameters()).device
-    with torch.no_grad():
-        if isinstance(model, ConvModel):
-            pred = model.forward_fused(body.to(dev), dif_encoding=dif_encoding, normalize=normalize,
-                                       denormalize=normalize, mask_tail=False)
-        else:  # steps/utils.py:180-210 then traintest.py:270-271, as device elementwise ops
-            x = body.to(dev)
-            if dif_encoding:
-                x = x - x[:, :, 1:2]
-            if normalize:
-                x = x / 1280
-            pred = model(x)
-            if normalize:
-                pred *= 1280
+    with torch.no_grad():   # steps/utils.py:180-210 and traintest.py:270-271 fused into the model's kernels
+        pred = model.forward_fused(body.to(dev), dif_encoding=dif_encoding, normalize=normalize,
+                                   denormalize=normalize, mask_tail=False)
     return pred.cpu().numpy(), [it["n_frames"] for it in items]
 
 

@@ -108,7 +108,7 @@ class TransformerEnc(nn.Module):
     def __del__(self):
         self._free()
 
-    def forward(self, src):
+    def _run(self, src, flags, factor, n_frames):
         lib = self._ensure_handle()
         if src.dim() != 4 or src.shape[2] * src.shape[3] != self.ninp:
             raise RuntimeError(f"expected input of shape (B, T, {self.ninp // 2}, 2), got {tuple(src.shape)}")
@@ -118,6 +118,13 @@ class TransformerEnc(nn.Module):
         dev = self.pose2hidden_projection.weight.device
         x = src.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
         B, T = x.shape[0], x.shape[1]
+        nf = None
+        if flags & _lib.POST_MASK_TAIL:
+            if n_frames is None:
+                raise ValueError("mask_tail needs n_frames")
+            nf = torch.as_tensor(n_frames).to(device=dev, dtype=torch.int64).contiguous()
+            if nf.shape != (B,):
+                raise RuntimeError(f"n_frames must have shape ({B},)")
         y = torch.empty((B, T, 21, 2), dtype=torch.float32, device=dev)
         need = lib.b2h_tenc_workspace_bytes(self._handle, B, T)
         ws = self.__dict__.get("_workspace")
@@ -127,6 +134,26 @@ class TransformerEnc(nn.Module):
         with _lib.on_device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.b2h_tenc_set_kernel(self._handle, TENC_KERNELS[self.precision]))
-            _lib.check(lib.b2h_tenc_forward(self._handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
-                                            B, T, ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(st)))
+            if flags == 0:
+                _lib.check(lib.b2h_tenc_forward(self._handle, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                                B, T, ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(st)))
+            else:
+                _lib.check(lib.b2h_tenc_forward_fused(self._handle, ctypes.c_void_p(x.data_ptr()),
+                                                      ctypes.c_void_p(y.data_ptr()), B, T, flags, float(factor),
+                                                      ctypes.c_void_p(nf.data_ptr()) if nf is not None else None,
+                                                      ctypes.c_void_p(ws.data_ptr()), ws.numel(), ctypes.c_void_p(st)))
         return y
+
+    def forward(self, src):
+        return self._run(src, 0, 1.0, None)
+
+    def forward_fused(self, body, n_frames=None, dif_encoding=True, normalize=True, denormalize=True,
+                      mask_tail=False, factor=1280.0):
+        """Raw-pixel body keypoints in, pixel-space hand keypoints out, with the item transforms inside
+        the model's own first and last kernel: ChestDifference + /factor (steps/utils.py:180-210) on the
+        rows as they enter (before the positional encoding, HandPoseModels.py:167) -> the encoder ->
+        x factor (traintest.py:270-271) and the optional tail mask (utils.py:309-312) in the store of
+        hidden2pose_projection's output.  Same flags as ConvModel.forward_fused."""
+        flags = ((_lib.PRE_CHEST_DIFF if dif_encoding else 0) | (_lib.PRE_NORMALIZE if normalize else 0) |
+                 (_lib.POST_DENORMALIZE if denormalize else 0) | (_lib.POST_MASK_TAIL if mask_tail else 0))
+        return self._run(body, flags, factor, n_frames)

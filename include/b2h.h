@@ -163,6 +163,16 @@ size_t b2h_tenc_workspace_bytes(const b2h_tenc* m, int64_t B, int64_t T);
 int b2h_tenc_forward(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* TransformerEnc forward with the reference's item transforms fused into its first and last kernel
+ * (SURVEY.md 8f N1 for the second model; order of run.py:85-90,102 and traintest.py:270-271):
+ *   body: device fp32 (B, T, 12, 2) raw pixel keypoints; flags / factor / n_frames as for
+ *   b2h_forward_fused -- B2H_PRE_CHEST_DIFF and B2H_PRE_NORMALIZE are applied to the rows as they
+ *   enter the model, BEFORE the positional encoding is added (HandPoseModels.py:167);
+ *   B2H_POST_DENORMALIZE and B2H_POST_MASK_TAIL in the store of hidden2pose_projection's output. */
+int b2h_tenc_forward_fused(b2h_tenc* m, const float* body, float* y, int64_t B, int64_t T, int flags,
+                           float factor, const int64_t* n_frames, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* Introspection / measurement -------------------------------------------- */
 
 /* conv_channels, pos_emb and whether weights are loaded. */

@@ -205,6 +205,41 @@ def tenc_cases(hpm):
     print("tenc params", sum(v.numel() for v in model.parameters()))
 
 
+def tenc_transform_case(utils, hpm, name, T, n_frames, seed):
+    """The item transforms around TransformerEnc exactly as run.py:83-107 / infer_utterance.py order
+    them for `--model TransformerEnc --dif-encoding`: WristDifference, ChestDifference,
+    NormalizeFixedFactor(1280), BuildRightHandItem (steps/utils.py:180-277) -> TransformerEnc
+    (HandPoseModels.py:152-178; the model of tenc_weights.npz, seed 41) -> x1280
+    (traintest.py:270-271) -> mask_output (steps/utils.py:309-312)."""
+    gen = torch.Generator().manual_seed(seed)
+    B = len(n_frames)
+    body = torch.rand((B, T, 12, 2), generator=gen) * torch.tensor([1280.0, 720.0])
+    rhand = torch.rand((B, T, 21, 2), generator=gen) * torch.tensor([1280.0, 720.0])
+    lhand = torch.rand((B, T, 21, 2), generator=gen) * torch.tensor([1280.0, 720.0])
+    torch.manual_seed(41)
+    model = hpm.TransformerEnc(ninp=12 * 2, nhead=4, nhid=128, nout=21 * 2, nlayers=4, dropout=0.5).eval()
+    rec = {"body": body.numpy(), "n_frames": np.array(n_frames)}
+    for tag, tf in (("dif", [utils.WristDifference(), utils.ChestDifference(), utils.NormalizeFixedFactor(1280),
+                             utils.BuildRightHandItem()]),
+                    ("nodif", [utils.NormalizeFixedFactor(1280), utils.BuildRightHandItem()])):
+        items = []
+        for b in range(B):
+            item = {"body_kp": body[b].clone(), "right_hand_kp": rhand[b].clone(), "left_hand_kp": lhand[b].clone(),
+                    "body_conf": torch.ones(T, 12), "right_hand_conf": torch.ones(T, 21)}
+            for t in tf:
+                item = t(item)
+            items.append(item)
+        inp = torch.stack([it["input_kp"] for it in items])
+        with torch.no_grad():
+            pred = model(inp).contiguous()
+            pred_px = pred * 1280
+            masked = utils.mask_output(pred_px.clone(), n_frames)
+        rec.update({tag + "_input_kp": inp.numpy(), tag + "_pred": pred.numpy(), tag + "_pred_px": pred_px.numpy(),
+                    tag + "_pred_px_masked": masked.numpy()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: body{tuple(body.shape)} -> pred_px{tuple(masked.shape)} |px|max={masked.abs().max():.2f}")
+
+
 def wire_formats_case(tpd, tt, name, seed):
     """The other two wire formats of SURVEY 8f N2, from the reference's own functions:
     merged JSON (frames as {"json_path", "json_data"} entries: How2Sign/util_scripts/build_dataset.py:66-72,
@@ -295,6 +330,7 @@ def main():
     transform_case(utils, hpm, "transforms_b6_t40", 40, [40, 1, 17, 39, 25, 8], 11)
     # TransformerEnc
     tenc_cases(hpm)
+    tenc_transform_case(utils, hpm, "tenc_transforms_b6_t40", 40, [40, 1, 17, 39, 25, 8], 13)
     # evaluation metric
     metric_case(utils, "metric_b5_t60", 5, 60, [60, 1, 33, 59, 17], 31)
     # OpenPose JSON wire format + utterance staging

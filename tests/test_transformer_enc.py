@@ -117,3 +117,64 @@ def test_f16x3_refuses_parameters_outside_f16_range(cuda_device):
     m.precision = "fp32"                                # the exact kernel takes the same weights
     with torch.no_grad():
         assert torch.isfinite(m(torch.from_numpy(x))).all()
+
+
+def _tfix():
+    d = np.load(os.path.join(GOLDEN, "tenc_transforms_b6_t40.npz"))
+    return {k: d[k] for k in d.files}
+
+
+@pytest.mark.parametrize("tag,dif", [("dif", True), ("nodif", False)])
+def test_oracle_transform_pipeline_matches_reference(tag, dif):
+    """The item transforms + TransformerEnc + x1280 + mask_output of the reference (its own classes,
+    tests/golden/make_golden.py:tenc_transform_case) against the oracle's restatement."""
+    state, _ = _load()
+    f = _tfix()
+    inp, _t = oracle.preprocess(f["body"], None, dif_encoding=dif, normalize=True)
+    assert np.array_equal(inp, f[tag + "_input_kp"])
+    pred = oracle.transformer_forward(inp, state)
+    assert np.abs(pred - f[tag + "_pred"]).max() <= 5e-6
+    px = oracle.postprocess(pred, 1280.0, f["n_frames"])
+    assert np.abs(px - f[tag + "_pred_px_masked"]).max() <= 5e-6 * 1280
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_hip_fused_transforms_match_reference(precision, cuda_device):
+    """TransformerEnc.forward_fused (transforms inside the chain kernel's front and store stages)
+    against the reference's transform classes + model (golden): raw pixels in, masked pixel
+    predictions out; and bit-identity with the unfused kernels on pre-transformed input."""
+    m, state, _ = _gpu_model(cuda_device, precision)
+    f = _tfix()
+    body = torch.from_numpy(f["body"]).to(cuda_device)
+    nf = f["n_frames"]
+    with torch.no_grad():
+        for tag, dif in (("dif", True), ("nodif", False)):
+            px = m.forward_fused(body, n_frames=nf, dif_encoding=dif, mask_tail=True).cpu().numpy()
+            px_nomask = m.forward_fused(body, dif_encoding=dif).cpu().numpy()
+            plain = m(torch.from_numpy(f[tag + "_input_kp"]).to(cuda_device))
+            assert np.abs(px - f[tag + "_pred_px_masked"]).max() <= TOL * 1280
+            assert np.abs(px_nomask - f[tag + "_pred_px"]).max() <= TOL * 1280
+            assert np.abs(plain.cpu().numpy() - f[tag + "_pred"]).max() <= TOL
+            for b, n in enumerate(nf):
+                assert not px[b, n:].any()
+            # the fused path computes the same bits as transform -> model -> x1280 done separately
+            assert np.array_equal(px_nomask, (plain * 1280).cpu().numpy())
+        # numerically neutral flags are bit-identical to the plain forward, at every length 1..100
+        g = torch.Generator().manual_seed(3)
+        for T in list(range(1, 34)) + [47, 48, 49, 63, 64, 65, 99, 100]:
+            x = (torch.rand((3, T, 12, 2), generator=g) - 0.5).to(cuda_device)
+            plain = m(x)
+            a = m.forward_fused(x, dif_encoding=False, normalize=False, denormalize=True, factor=1.0)
+            b = m.forward_fused(x, dif_encoding=False, normalize=False, denormalize=False, mask_tail=True, n_frames=[T] * 3)
+            assert torch.equal(a, plain) and torch.equal(b, plain), T
+        # ragged masks on a larger batch (frames span several workgroups), against the oracle
+        rng = np.random.default_rng(5)
+        bodyb = rng.random((37, 100, 12, 2), dtype=np.float32) * np.array([1280.0, 720.0], np.float32)
+        nfb = rng.integers(0, 101, 37)
+        out = m.forward_fused(torch.from_numpy(bodyb).to(cuda_device), n_frames=nfb, mask_tail=True).cpu().numpy()
+        inp, _t = oracle.preprocess(bodyb, None)
+        ref = oracle.postprocess(oracle.transformer_forward(inp, state), 1280.0, nfb)
+        assert np.abs(out - ref).max() <= TOL * 1280
+        with pytest.raises(ValueError):
+            m.forward_fused(body, mask_tail=True)                    # needs n_frames
