@@ -25,15 +25,19 @@ namespace b2h {
 constexpr int kImg3 = kRows * 64; // bytes of one image (hi or lo) of a wave
 
 
-// hi = f16(v) packed two per instruction, residual v - hi as one mixed-precision FMA per value
-// (v_fma_mix_f32 reads the f16 half directly), lo = f16(residual) packed: 16 VALU for 8 values
+// hi = f16(v) packed two per instruction (v_cvt_pk_f16_f32), residual v - hi as ONE mixed-precision
+// FMA per value (v_fma_mix_f32 reads the f16 half straight out of the packed register; written as
+// asm because hipcc otherwise converts hi back with v_cvt_f32_f16 and subtracts), lo = f16(residual)
+// packed: 16 VALU for 8 values.
 __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f16x2 h = f16x2{(_Float16)v[2 * i], (_Float16)v[2 * i + 1]};
-        const float r0 = __builtin_fmaf((float)h[0], -1.0f, v[2 * i]);
-        const float r1 = __builtin_fmaf((float)h[1], -1.0f, v[2 * i + 1]);
+        const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(v[2 * i]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(v[2 * i + 1]));
         const f16x2 l = f16x2{(_Float16)r0, (_Float16)r1};
         hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
         lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];

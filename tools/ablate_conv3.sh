@@ -4,7 +4,7 @@
 #   bash tools/ablate_conv3.sh > gpurun_out/ablate_conv3.txt
 set -e
 cd "$(dirname "$0")/.."
-for a in 0 64 128 192; do
+for a in ${ABLATE_BITS:-0 64 128 192}; do
   B2H_ABLATE=$a python -m hand_pose_sl_amd.build --force > /dev/null 2>&1
   python - <<PY
 import torch, hand_pose_sl_amd as hps
@@ -15,7 +15,7 @@ x = torch.rand((65536, 200, 12, 2), device=dev) - 0.5
 y = torch.empty((65536, 200, 21, 2), device=dev)
 m.time_forward(x, y, 5)
 ms = min(m.time_forward(x, y, 20) for _ in range(3))
-print(f"B2H_ABLATE=$a  f16x3 65536x200: {ms:.4f} ms  {65536*200/ms/1e6:.2f} G frames/s", flush=True)
+print(f"B2H_ABLATE=$a  {m.kernel_name()} 65536x200: {ms:.4f} ms  {65536*200/ms/1e6:.2f} G frames/s", flush=True)
 PY
 done
 B2H_ABLATE= python -m hand_pose_sl_amd.build --force > /dev/null 2>&1
