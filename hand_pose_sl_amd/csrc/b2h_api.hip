@@ -19,7 +19,6 @@
 #include "kernel_mfma16.h"
 #include "kernel_mfma16w.h"
 #include "kernel_mfma3.h"
-#include "kernel_mfma3p.h"
 #include "kernel_tenc.h"
 #include "kernel_valu.h"
 
@@ -127,7 +126,6 @@ struct b2h_model {
     DevBuf valu_w[4], valu_b[4];
     DevBuf mf32_w[4], m_bias[4];  // exact-fp32 MFMA kernel: per-layer fragments + bias fragments
     DevBuf m3_w[4];               // f16x3 kernel: per-layer hi / lo f16 fragments (bias shared)
-    DevBuf m3p_all;               // persistent f16x3 kernel: [W hi|lo L0..L3 | bias L0..L3], kPacked3p bytes
     DevBuf mbf16_all, mf16_all;   // persistent 16-bit kernel: [W L0..L3 | bias L0..L3], kPacked16 bytes
     DevBuf mwbf_w[4], mwh_w[4], mw_bias[4]; // wide 16-bit kernel (33..64 channels): bf16 / f16 fragments, bias
     int num_cus = 256;
@@ -232,7 +230,6 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
 
     // ---- MFMA layouts
     std::vector<unsigned char> ab(kPacked16, 0), ah(kPacked16, 0); // LDS images of the persistent kernel
-    std::vector<unsigned char> a3(kPacked3p, 0);                   // LDS image of the persistent f16x3 kernel
     for (int l = 0; l < 4; ++l) {
         const int MT = (l == 3) ? 3 : 2;
         auto chan = [&](int mt, int row) { return l == 3 ? last_chan_of(mt, row) : hidden_chan_of(mt, row); };
@@ -276,8 +273,6 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
                         w3[at] = hi;
                         w3[at + 64 * 8] = (_Float16)(v - (float)hi);
                     }
-        std::memcpy(a3.data() + kWLayerOff3p[l], w3.data(), w3.size() * 2);
-        std::memcpy(a3.data() + kBiasOff3p[l], bf.data(), bf.size() * 4);
         int rc;
         if ((rc = m->mf32_w[l].upload(wf.data(), wf.size() * 4))) return rc;
         if ((rc = m->m_bias[l].upload(bf.data(), bf.size() * 4))) return rc;
@@ -292,7 +287,6 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
     int rc;
     if ((rc = m->mbf16_all.upload(ab.data(), ab.size()))) return rc;
     if ((rc = m->mf16_all.upload(ah.data(), ah.size()))) return rc;
-    if ((rc = m->m3p_all.upload(a3.data(), a3.size()))) return rc;
     return B2H_OK;
 }
 
@@ -330,7 +324,6 @@ int set_conv_kernel_attributes() {
     int rc;
     if ((rc = raise_lds_cap(b2h_fwd_f32_valu<true>)) || (rc = raise_lds_cap(b2h_fwd_f32_valu<false>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma_f32)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3)) ||
-        (rc = raise_lds_cap(b2h_fwd_mfma_f16x3p<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3p<true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_BF16>)) || (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_F16>)))
@@ -387,29 +380,6 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         // bit-identical frames.
         const bool wide = m->C > kMfmaWidth; // 33..64 channels: wave-per-chunk 16-bit kernel (kernel_mfma16w.h)
         int chunk_len = kChunk;
-        static const bool f16x3_chunk_kernel = std::getenv("B2H_F16X3_CHUNK_KERNEL") != nullptr; // dev A/B only
-        if (k == B2H_KERNEL_F16X3_MFMA && !f16x3_chunk_kernel) {
-            // persistent form: one 256-thread workgroup per CU, chunks of <= 112 frames; shorter chunks
-            // when the batch would leave most of the chip's 4 x CUs wave slots idle
-            int TT = kChunk3p;
-            int64_t nch = B * ((T + TT - 1) / TT);
-            const int64_t slots = (int64_t)m->num_cus * kWaves3p;
-            for (int cand : {64, 32}) {
-                if (nch * 2 >= slots || T <= cand) break;
-                TT = cand;
-                nch = B * ((T + TT - 1) / TT);
-            }
-            const int cps3 = (int)((T + TT - 1) / TT);
-            const unsigned grid3 = (unsigned)std::min<int64_t>(m->num_cus, nch);
-            if (fa.flags)
-                hipLaunchKernelGGL(b2h_fwd_mfma_f16x3p<true>, dim3(grid3), dim3(64 * kWaves3p), kLds3p, st, x, y, (int)T,
-                                   cps3, TT, nch, m->m3p_all.p, m->pos_emb, fa);
-            else
-                hipLaunchKernelGGL(b2h_fwd_mfma_f16x3p<false>, dim3(grid3), dim3(64 * kWaves3p), kLds3p, st, x, y, (int)T,
-                                   cps3, TT, nch, m->m3p_all.p, m->pos_emb, fa);
-            HIP_TRY(hipGetLastError());
-            return B2H_OK;
-        }
         if (wide || (k != B2H_KERNEL_BF16_MFMA && k != B2H_KERNEL_F16_MFMA)) {
             const int64_t slots = (int64_t)m->num_cus * 2 * kWavesPerBlock;
             for (int cand : {64, 32}) {
@@ -892,7 +862,7 @@ const char* b2h_kernel_name(const b2h_model* m, int kernel) {
         case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma_f32";
         case B2H_KERNEL_BF16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<1>" : "b2h_fwd_mfma16<1, false>";
         case B2H_KERNEL_F16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<2>" : "b2h_fwd_mfma16<2, false>";
-        case B2H_KERNEL_F16X3_MFMA: return "b2h_fwd_mfma_f16x3p<false>";
+        case B2H_KERNEL_F16X3_MFMA: return "b2h_fwd_mfma_f16x3";
         default: return "";
     }
 }

@@ -10,9 +10,7 @@
 //     16384 s_memtime stamps of one workgroup's phases (tools/chain_stamps.py);
 //   f16x3 conv kernel: 32768 s_memtime stamps of one wave's phases (tools/conv3_stamps.py),
 //     64 one weight fragment per layer instead of 20-30 (prices the per-chunk weight reloads from L2),
-//     128 no input loads;
-//   persistent f16x3 kernel (kernel_mfma3p.h): 256 no tile epilogue, 512 no fragment reads,
-//     1024 one MFMA per tap and M-tile instead of three.
+//     128 no input loads.
 #pragma once
 #ifndef B2H_ABLATE
 #define B2H_ABLATE 0
@@ -26,14 +24,8 @@ __device__ unsigned long long g_conv3_dbg[4 * 16];
     do {                                                                                                    \
         if (blockIdx.x == gridDim.x / 2 && (cx).lane == 0) g_conv3_dbg[(threadIdx.x >> 6) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
-// persistent form: stamps of the middle workgroup's waves in their THIRD chunk (steady state)
-#define B2H_STAMP3P(k)                                                                                      \
-    do {                                                                                                    \
-        if (blockIdx.x == gridDim.x / 2 && lane == 0 && dbg_iter == 2) g_conv3_dbg[(threadIdx.x >> 6) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
 #else
 #define B2H_STAMP3(cx, k) do { } while (0)
-#define B2H_STAMP3P(k) do { } while (0)
 #endif
 
 #if B2H_ABLATE & 16384

@@ -225,12 +225,20 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
 
     const int pin = 8 - 2 * L - g.s; // P(t, L)   = t + pin
     const int pout = pin - 2;        // P(t, L+1) = t + pout
-    // fragment addresses of tile 0; a tile step is 16 rows = 1024 B and leaves the
-    // swizzle term ((P>>1)&3) unchanged
-    int rd[kTaps];
+    // Fragment byte offsets of the tile the loop stands at; a tile step is 16 rows = 1024 B and
+    // leaves the swizzle term ((P>>1)&3) unchanged.  They advance once per loop iteration and are made
+    // opaque there, so every LDS access below is register + immediate offset (left to itself hipcc's
+    // loop strength reduction keeps one address register per access and re-adds each per iteration).
+    // (Held as 32-bit LDS pointers, so the registers ARE the addresses and no base add remains.)
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) const vec8 lds_vec8;
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    lds_char* rd[kTaps];
 #pragma unroll
-    for (int s = 0; s < kTaps; ++s) rd[s] = lds_off<64>(lo + tcol + s - kPad + pin, q);
-    int wr = lds_off<64>(lo + tcol + pout, q);
+    for (int s = 0; s < kTaps; ++s) rd[s] = (lds_char*)(lds + lds_off<64>(lo + tcol + s - kPad + pin, q));
+    lds_char* wr = (lds_char*)(lds + lds_off<64>(lo + tcol + pout, q));
+    int tq = lo + tcol;  // this lane's frame in the tile the loop stands at
+    int sbase = 0;       // head: byte offset of that tile's rows in the output buffer (wave-uniform)
 
     // head only: this chunk's output rows [s, e) as a buffer (so that byte offsets stay small
     // however long the sequence is), lane byte offset within tile 0
@@ -251,28 +259,29 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
                 acc[mt] = P::mfma(A[mt][s], Bf[s], acc[mt]);
             }
     };
-    // E: epilogue of tile m.
-    auto epi = [&](const f32x4 (&acc)[MT], int m) {
-        const int tau = lo + 16 * m;
+    // E: epilogue of the tile k tiles past the one the loop stands at (k is a constant at every call).
+    // `mask`: only the LAST tile of a layer can hold frames >= T, and the loop below never runs a last
+    // tile's epilogue, so its body carries no padding mask and no branch.
+    auto epi = [&](const f32x4 (&acc)[MT], int k, bool mask) {
         if constexpr (L < 3) {
             float v[8];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[mt * 4 + r] = relu_bits(acc[mt][r]);
-            if (tau + 16 > T) { // only the last tile can hold frames >= T (zero padding of the next layer)
-                const bool inside = tau + tcol < T;
+            if (mask) { // frames >= T are the zero padding of the next layer
+                const bool inside = tq + 16 * k < T;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = inside ? v[k] : 0.f;
+                for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.f;
             }
-            uint4 o = {pack2<PREC>(v[0], v[1]), pack2<PREC>(v[2], v[3]), pack2<PREC>(v[4], v[5]),
-                       pack2<PREC>(v[6], v[7])};
-            *reinterpret_cast<uint4*>(lds + wr + m * 1024) = o;
+            const u32x4 o = {pack2<PREC>(v[0], v[1]), pack2<PREC>(v[2], v[3]), pack2<PREC>(v[4], v[5]),
+                             pack2<PREC>(v[6], v[7])};
+            *(lds_u32x4*)(wr + k * 1024) = o;
         } else {
             {
-                // lane (tcol,q) owns channels 16mt + 4q .. +3 of frame tau + tcol: 16 B at
+                // lane (tcol,q) owns channels 16mt + 4q .. +3 of its frame: 16 B at
                 // row offset 168 (t - s) + 64 mt + 16 q; frames >= e fall outside the descriptor
-                const bool dead = FUSED && (tau + tcol >= nvalid); // tail mask (per lane)
+                const bool dead = FUSED && (tq + 16 * k >= nvalid); // tail mask (per lane)
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) {
                     f32x4 v = acc[mt];
@@ -280,7 +289,7 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
                         v = v * mul;                               // x factor, or x 1.0f (exact)
                         if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    const int so = m * (16 * kOutCh * 4) + mt * 64;
+                    const int so = sbase + k * (16 * kOutCh * 4) + mt * 64;
                     if constexpr (FUSED) __builtin_amdgcn_sched_barrier(0); // store + its wait states stay adjacent (below)
                     if (mt < 2 || q < 2)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff, so, 0);
@@ -307,14 +316,23 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
             }
         }
     };
-    // F: tile m's five fragments.  Unconditional: past the last tile it reads rows that
-    // nobody uses (LDS reads beyond the allocation return 0), which keeps the loop free
+    // F: the five fragments of the tile k tiles ahead.  Unconditional: past the last tile it reads
+    // rows that nobody uses (LDS reads beyond the allocation return 0), which keeps the loop free
     // of branches between the MFMAs and the epilogue they overlap with.
-    auto fetch = [&](vec8 (&Bf)[kTaps], int m) {
+    auto fetch = [&](vec8 (&Bf)[kTaps], int k) {
+#pragma unroll
+        for (int s = 0; s < kTaps; ++s) Bf[s] = *(lds_vec8*)(rd[s] + k * 1024);
+    };
+    auto advance2 = [&]() { // two tiles on
 #pragma unroll
         for (int s = 0; s < kTaps; ++s) {
-            Bf[s] = *reinterpret_cast<const vec8*>(lds + rd[s] + m * 1024);
+            rd[s] += 2048;
+            asm volatile("" : "+v"(rd[s]));
         }
+        wr += 2048;
+        asm volatile("" : "+v"(wr));
+        tq += 32;
+        sbase += 2 * (16 * kOutCh * 4);
     };
     // Software pipeline over tiles, two deep: fragments are read two tiles ahead (ping-pong
     // B0/B1) and a tile's epilogue runs one tile late (ping-pong accA/accB), next to the
@@ -328,14 +346,15 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
     fetch(B1, 1);
     mma(accA, B0); // tile 0
     fetch(B0, 2);
-    int m = 1;
+    int m = 1; // the offsets stand at tile m - 1
 #pragma unroll 1
     for (; m + 1 < ntiles; m += 2) {
-        mma(accB, B1); epi(accA, m - 1); fetch(B1, m + 2);
-        mma(accA, B0); epi(accB, m);     fetch(B0, m + 3);
+        mma(accB, B1); epi(accA, 0, false); fetch(B1, 3);
+        mma(accA, B0); epi(accB, 1, false); fetch(B0, 4);
+        advance2();
     }
-    if (m < ntiles) { mma(accB, B1); epi(accA, m - 1); epi(accB, m); }
-    else epi(accA, m - 1);
+    if (m < ntiles) { mma(accB, B1); epi(accA, 0, false); epi(accB, 1, true); }
+    else epi(accA, 0, true);
     if constexpr (L < 3) {
         if (hi == T) { // sequence end: next layer reads frames T, T+1 as zeros
             const int t = T + (lane >> 2);

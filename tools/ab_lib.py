@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""GPU box: same-process A/B of two builds of libb2h.so on the bench shape, interleaved rounds
+(cdna_hip_programming.md rule 24).  Each library is loaded under its own ctypes handle.
+    python tools/ab_lib.py <libA.so> <libB.so> [precision=bf16] [seqs=65536] [T=200]"""
+import ctypes, os, sys, statistics
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hand_pose_sl_amd import _lib
+
+paths = sys.argv[1:3]
+prec = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+S = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
+T = int(sys.argv[5]) if len(sys.argv) > 5 else 200
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+import torch.nn as nn
+convs = [nn.Conv1d(24, 30, 5, padding=2), nn.Conv1d(30, 30, 5, padding=2), nn.Conv1d(30, 30, 5, padding=2), nn.Conv1d(30, 42, 5, padding=2)]
+ps = [p.detach().to(dev).contiguous() for c in convs for p in (c.weight, c.bias)]
+x = torch.rand((S, T, 12, 2), device=dev) - 0.5
+ys = []
+libs = []
+for p in paths:
+    lib = ctypes.CDLL(os.path.abspath(p))
+    for name, (res, args) in _lib.SYMBOLS.items():
+        if hasattr(lib, name):
+            getattr(lib, name).restype = res
+            getattr(lib, name).argtypes = args
+    h = ctypes.c_void_p()
+    assert lib.b2h_create(30, b"ReLU", 0, ctypes.byref(h)) == 0
+    assert lib.b2h_load_weights(h, *[ctypes.c_void_p(t.data_ptr()) for t in ps], 1) == 0
+    y = torch.empty((S, T, 21, 2), device=dev)
+    libs.append((lib, h, y))
+k = _lib.KERNELS[prec]
+def t(lib, h, y, iters):
+    ms = ctypes.c_float()
+    rc = lib.b2h_time_forward(h, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), S, T, k, iters, None, ctypes.byref(ms))
+    assert rc == 0, lib.b2h_last_error()
+    return ms.value
+for lib, h, y in libs:
+    t(lib, h, y, 20)
+res = [[], []]
+for r in range(12):
+    for i, (lib, h, y) in enumerate(libs):
+        res[i].append(t(lib, h, y, 40))
+torch.cuda.synchronize()
+print("outputs identical:", torch.equal(libs[0][2], libs[1][2]))
+for i, p in enumerate(paths):
+    print(f"{p}: median {statistics.median(res[i])*1e3:.1f} us  min {min(res[i])*1e3:.1f} us  ({S*T/statistics.median(res[i])/1e6:.2f} G frames/s)")

@@ -19,9 +19,7 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 64)()
 assert _lib.load().b2h_debug_conv3_stamps(buf) == 0
 a = np.array(buf[:], dtype=np.uint64).reshape(4, 16).astype(np.int64)
-persistent = "f16x3p" in m.kernel_name()
-names = (["commit", "issue loads", "L0", "L1", "L2", "wait loads", "L3 (head)"] if persistent else
-         ["stage"] + [f"L{l}:{p}" for l in range(4) for p in ("w", "tiles")])
+names = ["stage"] + [f"L{l}:{p}" for l in range(4) for p in ("w", "tiles")]
 for w in range(4):
-    d = np.diff(a[w][:8 if persistent else 10])
+    d = np.diff(a[w][:10])
     print("wave", w, " ".join(f"{n}={v}" for n, v in zip(names, d.tolist())), " total", int(d.sum()))
