@@ -198,6 +198,10 @@ int pack_wide(b2h_model* m, const HostWeights& hw) {
     return B2H_OK;
 }
 
+// single-parameter aliases of the wide kernel for the launch macro
+template <bool FUSED> constexpr auto b2h_fwd_mfma16w_bf16 = b2h_fwd_mfma16w<PREC_BF16, FUSED>;
+template <bool FUSED> constexpr auto b2h_fwd_mfma16w_f16 = b2h_fwd_mfma16w<PREC_F16, FUSED>;
+
 int pack_all(b2h_model* m, const HostWeights& hw) {
     m->w_absmax = 0.f;
     for (int l = 0; l < 4; ++l) m->w_absmax = absmax_of(hw.b[l], absmax_of(hw.w[l], m->w_absmax));
@@ -323,10 +327,12 @@ int set_conv_kernel_attributes() {
     if (dev >= 0 && dev < 64 && done[dev]) return B2H_OK;
     int rc;
     if ((rc = raise_lds_cap(b2h_fwd_f32_valu<true>)) || (rc = raise_lds_cap(b2h_fwd_f32_valu<false>)) ||
-        (rc = raise_lds_cap(b2h_fwd_mfma_f32)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma_f32<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f32<true>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma_f16x3<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3<true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, true>)) ||
-        (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_BF16>)) || (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_F16>)))
+        (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_BF16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_BF16, true>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_F16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_F16, true>)))
         return rc;
     if (dev >= 0 && dev < 64) done[dev] = true;
     return B2H_OK;
@@ -392,18 +398,22 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         const int64_t grid = (nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
         if (grid > 0x7fffffff) return fail(B2H_ERR_SHAPE, "B*T too large for one launch");
         const dim3 g((unsigned)grid), blk(64 * kWavesPerBlock);
+        const bool fusedc = fa.flags != 0; // the plain instantiations carry no transform code at all
+#define B2H_LAUNCHC(KERN, LDS, MP)                                                                          \
+    do {                                                                                                    \
+        if (fusedc) hipLaunchKernelGGL((KERN<true>), g, blk, LDS, st, x, y, (int)T, cps, chunk_len, nchunks, MP, fa);  \
+        else hipLaunchKernelGGL((KERN<false>), g, blk, LDS, st, x, y, (int)T, cps, chunk_len, nchunks, MP, fa);        \
+    } while (0)
         if (wide) {
             const size_t lds = (size_t)kWavesPerBlock * kImgW;
-            if (k == B2H_KERNEL_BF16_MFMA)
-                hipLaunchKernelGGL(b2h_fwd_mfma16w<PREC_BF16>, g, blk, lds, st, x, y, (int)T, cps, chunk_len, nchunks, m->mpw_bf, fa);
-            else
-                hipLaunchKernelGGL(b2h_fwd_mfma16w<PREC_F16>, g, blk, lds, st, x, y, (int)T, cps, chunk_len, nchunks, m->mpw_h, fa);
+            if (k == B2H_KERNEL_BF16_MFMA) B2H_LAUNCHC(b2h_fwd_mfma16w_bf16, lds, m->mpw_bf);
+            else B2H_LAUNCHC(b2h_fwd_mfma16w_f16, lds, m->mpw_h);
         } else if (k == B2H_KERNEL_F32_MFMA) {
             const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_F32>::kRowBytes;
-            hipLaunchKernelGGL(b2h_fwd_mfma_f32, g, blk, lds, st, x, y, (int)T, cps, chunk_len, nchunks, m->mp32, fa);
+            B2H_LAUNCHC(b2h_fwd_mfma_f32, lds, m->mp32);
         } else if (k == B2H_KERNEL_F16X3_MFMA) {
             const size_t lds = (size_t)kWavesPerBlock * 2 * kImg3; // hi + lo images = the fp32 image's bytes
-            hipLaunchKernelGGL(b2h_fwd_mfma_f16x3, g, blk, lds, st, x, y, (int)T, cps, chunk_len, nchunks, m->mp3, fa);
+            B2H_LAUNCHC(b2h_fwd_mfma_f16x3, lds, m->mp3);
         } else {
             // persistent kernel: one 512-thread workgroup per CU
             // Chunk length: whole sequences (<= 208 frames) or 192-frame chunks keep the halo
@@ -432,6 +442,7 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             else B2H_LAUNCH16(PREC_F16, true);
 #undef B2H_LAUNCH16
         }
+#undef B2H_LAUNCHC
     }
     HIP_TRY(hipGetLastError());
     return B2H_OK;
@@ -859,10 +870,10 @@ const char* b2h_kernel_name(const b2h_model* m, int kernel) {
     if (!m) return "";
     switch (resolve_kernel(m, kernel)) {
         case B2H_KERNEL_F32_VALU: return "b2h_fwd_f32_valu";
-        case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma_f32";
-        case B2H_KERNEL_BF16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<1>" : "b2h_fwd_mfma16<1, false>";
-        case B2H_KERNEL_F16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<2>" : "b2h_fwd_mfma16<2, false>";
-        case B2H_KERNEL_F16X3_MFMA: return "b2h_fwd_mfma_f16x3";
+        case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma_f32<false>";
+        case B2H_KERNEL_BF16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<1, false>" : "b2h_fwd_mfma16<1, false>";
+        case B2H_KERNEL_F16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<2, false>" : "b2h_fwd_mfma16<2, false>";
+        case B2H_KERNEL_F16X3_MFMA: return "b2h_fwd_mfma_f16x3<false>";
         default: return "";
     }
 }

@@ -91,22 +91,29 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, in
 // outside the descriptor and are dropped by the range check, channels 40, 41 are an 8-byte store.
 // Every offset that varies is in the VGPR offset (immediate soffset), so hipcc pads the store-data
 // write-after-read hazard itself (tests/test_isa_audit.py).
-struct HeadStore {
+// FUSED: x factor (traintest.py:387-388) and the tail mask (utils.py:309-312); the plain
+// instantiation carries neither the multiplies nor the selects.
+template <bool FUSED> struct HeadStore {
     __amdgpu_buffer_rsrc_t rs;
-    int off, t0;
+    int off, t0; // byte offset / frame of this lane in the tile the caller stands at
+    float mul;
     __device__ __forceinline__ void init(const ChunkCtx& cx, int lo) { // lo == cx.s for the head
         rs = make_rsrc(cx.y + (int64_t)lo * kOutCh, (cx.e - lo) * (kOutCh * 4));
         off = cx.tcol * (kOutCh * 4) + 16 * cx.q;
         t0 = lo + cx.tcol;
+        mul = (cx.fa.flags & kPostDenorm) ? cx.fa.factor : 1.0f; // x 1.0f is exact
     }
-    __device__ __forceinline__ void store(const ChunkCtx& cx, const f32x4 (&acc)[3], int m) {
-        const bool dead = (int64_t)(t0 + 16 * m) >= cx.nvalid; // tail mask (utils.py:309-312)
-        const int vo = off + m * (16 * kOutCh * 4);
+    __device__ __forceinline__ void advance2() { off += 2 * (16 * kOutCh * 4); t0 += 32; }
+    __device__ __forceinline__ void store(const ChunkCtx& cx, const f32x4 (&acc)[3], int k) { // tile k past the caller's
+        const bool dead = FUSED && (int64_t)(t0 + 16 * k) >= cx.nvalid;
+        const int vo = off + k * (16 * kOutCh * 4);
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) {
             f32x4 v = acc[mt];
-            if (cx.fa.flags & kPostDenorm) v = v * cx.fa.factor;     // traintest.py:387-388
-            if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (FUSED) {
+                v = v * mul;
+                if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             if (mt < 2 || cx.q < 2)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, vo + 64 * mt, 0, 0);
             else if (cx.q == 2) // channels 40, 41 (elements passed BY VALUE: see kernel_mfma16.h)
@@ -117,7 +124,7 @@ struct HeadStore {
 };
 
 // ---- exact-fp32 layers (v_mfma_f32_16x16x4_f32) -------------------------------
-template <int L>
+template <int L, bool FUSED>
 __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp) {
     constexpr int MT = (L == 3) ? 3 : 2;
     constexpr int h = 6 - 2 * L;
@@ -140,7 +147,7 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
     }
     const int pin = 8 - 2 * L - cx.s;
     const int pout = pin - 2;
-    HeadStore hs;
+    HeadStore<FUSED> hs;
     if constexpr (L == 3) hs.init(cx, lo);
 
 #pragma unroll 1
@@ -181,7 +188,9 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
             for (int mt = 0; mt < 2; ++mt) // channels 8q + 4mt .. +3  ->  16-B chunk 2q + mt
                 *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(t + pout, 2 * cx.q + mt)) = o[mt];
         } else {
-            hs.store(cx, acc, m);
+            hs.store(cx, acc, 0);
+            hs.off += 16 * kOutCh * 4;
+            hs.t0 += 16;
         }
     }
     if constexpr (L < 3) {
@@ -254,6 +263,7 @@ __device__ __forceinline__ void stage_input32(const ChunkCtx& cx, const float* _
 
 // One wave per (sequence, chunk); no workgroup barrier anywhere.  Two 4-wave workgroups per CU by
 // LDS = 2 waves per SIMD, so a wave may use 256 VGPRs (keeps the accumulators out of AGPRs).
+template <bool FUSED>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma_f32(
     const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq, int chunk_len,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma_f32(
     cx.nvalid = T;
     if ((fa.flags & kPostMask) && fa.n_frames) cx.nvalid = fa.n_frames[cx.seq];
     stage_input32(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
-    layer32<0>(cx, mp); layer32<1>(cx, mp); layer32<2>(cx, mp); layer32<3>(cx, mp);
+    layer32<0, FUSED>(cx, mp); layer32<1, FUSED>(cx, mp); layer32<2, FUSED>(cx, mp); layer32<3, FUSED>(cx, mp);
 }
 
 } // namespace b2h

@@ -38,7 +38,7 @@ __device__ __forceinline__ int lds_offw(int P, int c) { return P * kWideRowB + (
 __host__ __device__ constexpr int wide_mt(int L) { return L == 3 ? 3 : kWideMT; }
 __host__ __device__ constexpr int wide_ks(int L) { return L == 0 ? 1 : 2; }
 
-template <int PREC, int L>
+template <int PREC, int L, bool FUSED>
 __device__ __forceinline__ void layer16w(const ChunkCtx& cx, const MfmaParams& mp) {
     using P = Prec<PREC>;
     using vec8 = typename P::vec8;
@@ -70,7 +70,7 @@ __device__ __forceinline__ void layer16w(const ChunkCtx& cx, const MfmaParams& m
 #pragma unroll
     for (int s = 0; s < kTaps; ++s) roff[s] = lds_offw(lo + cx.tcol + s - kPad + pin, cx.q);
     const int woff = lds_offw(lo + cx.tcol + pout, 2 * cx.q);
-    HeadStore hs;
+    HeadStore<FUSED> hs;
     if constexpr (L == 3) hs.init(cx, lo);
 
 #pragma unroll 1
@@ -105,7 +105,9 @@ __device__ __forceinline__ void layer16w(const ChunkCtx& cx, const MfmaParams& m
                 *reinterpret_cast<uint4*>(cx.lds + ((woff + m * (16 * kWideRowB)) ^ (16 * hh))) = o;
             }
         } else {
-            hs.store(cx, acc, m);
+            hs.store(cx, acc, 0);
+            hs.off += 16 * kOutCh * 4;
+            hs.t0 += 16;
         }
     }
     if constexpr (L < 3) {
@@ -176,7 +178,7 @@ __device__ __forceinline__ void stage_input16w(const ChunkCtx& cx, const float* 
 
 // One wave per (sequence, chunk); no workgroup barrier anywhere.  18 KB of LDS per wave: two 4-wave
 // workgroups per CU = 2 waves per SIMD, each within 256 VGPRs.
-template <int PREC>
+template <int PREC, bool FUSED>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma16w(
     const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq, int chunk_len,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
@@ -200,7 +202,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma16w(
     cx.nvalid = T;
     if ((fa.flags & kPostMask) && fa.n_frames) cx.nvalid = fa.n_frames[cx.seq];
     stage_input16w<PREC>(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
-    layer16w<PREC, 0>(cx, mp); layer16w<PREC, 1>(cx, mp); layer16w<PREC, 2>(cx, mp); layer16w<PREC, 3>(cx, mp);
+    layer16w<PREC, 0, FUSED>(cx, mp); layer16w<PREC, 1, FUSED>(cx, mp);
+    layer16w<PREC, 2, FUSED>(cx, mp); layer16w<PREC, 3, FUSED>(cx, mp);
 }
 
 } // namespace b2h

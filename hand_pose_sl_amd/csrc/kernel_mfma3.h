@@ -44,14 +44,24 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
     }
 }
 
-template <int L>
+// One layer over this wave's chunk.  Software pipeline over 16-frame tiles, two deep: fragments are
+// read two tiles ahead (ping-pong B0/B1), a tile's epilogue runs one tile late (ping-pong accA/accB)
+// beside the following tile's MFMAs, and sched_group_barrier spreads that vector / LDS work between
+// the MFMAs one at a time (tools/mfma_mix_bench.hip: per MFMA one VALU is free on this chip, a run of
+// VALU after a run of MFMAs costs the sum).  Legal in the in-place image: tile m writes rows
+// [tau-2, tau+14) of the next image, every fragment read issued before that write belongs to tiles
+// <= m+2, and tiles > m read rows >= tau+14.  Only a layer's LAST tile can hold frames >= T and the
+// loop never runs a last tile's epilogue, so its body has no padding mask and no branch.
+// FUSED: the output-side item transforms (x factor, tail mask) exist only in that instantiation.
+template <int L, bool FUSED>
 __device__ __forceinline__ void layer3(const ChunkCtx& cx, const MfmaParams& mp) {
     constexpr int MT = (L == 3) ? 3 : 2;
     constexpr int h = 6 - 2 * L;
     const int lo = max(cx.s - h, 0), hi = min(cx.e + h, cx.T);
     const int ntiles = (hi - lo + 15) >> 4;
-    char* img_h = cx.lds;
-    char* img_l = cx.lds + kImg3;
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) const f16x8 lds_cf16x8;
+    typedef __attribute__((address_space(3))) f16x8 lds_f16x8;
 
     f16x8 Ah[MT][kTaps], Al[MT][kTaps]; // [.][tap]: in-channels 8q + j of out-channel slot (lane & 15)
     f32x4 bias[MT];
@@ -71,57 +81,101 @@ __device__ __forceinline__ void layer3(const ChunkCtx& cx, const MfmaParams& mp)
     B2H_STAMP3(cx, 2 + 2 * L); // weight fragments requested
     const int pin = 8 - 2 * L - cx.s;
     const int pout = pin - 2;
-    // Tiles advance by 16 rows and the image's chunk swizzle has period 8, so the swizzled byte
-    // offsets of this lane's five tap rows (and of its write-back row) are those of tile 0 plus
-    // m * 1024: computed once per layer, one add per tile.
-    int roff[kTaps];
+    // Fragment addresses as 32-bit LDS pointers into the hi image (the lo image is kImg3 bytes further;
+    // a tile step is 16 rows = 1024 B and leaves the swizzle unchanged).  They advance once per loop
+    // iteration and are made opaque there, so every access is register + immediate offset.
+    lds_char* rp[kTaps];
 #pragma unroll
-    for (int s = 0; s < kTaps; ++s) roff[s] = lds_off<64>(lo + cx.tcol + s - kPad + pin, cx.q);
-    int woff = lds_off<64>(lo + cx.tcol + pout, cx.q);
-    HeadStore hs;
+    for (int s = 0; s < kTaps; ++s) rp[s] = (lds_char*)(cx.lds + lds_off<64>(lo + cx.tcol + s - kPad + pin, cx.q));
+    lds_char* wp = (lds_char*)(cx.lds + lds_off<64>(lo + cx.tcol + pout, cx.q));
+    int tq = lo + cx.tcol; // this lane's frame in the tile the loop stands at
+    HeadStore<FUSED> hs;
     if constexpr (L == 3) hs.init(cx, lo);
 
-#pragma unroll 1
-    for (int m = 0; m < ntiles; ++m) {
-        const int tau = lo + 16 * m;
-        f32x4 acc[MT];
+    auto mma = [&](f32x4 (&acc)[MT], const f16x8 (&Bh)[kTaps], const f16x8 (&Bl)[kTaps]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = bias[mt];
 #pragma unroll
         for (int s = 0; s < kTaps; ++s) {
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(img_h + roff[s]);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(img_l + roff[s]);
-            roff[s] += 16 * 64;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[mt][s], bh, acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[mt][s], Bh[s], acc[mt], 0, 0, 0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt][s], bl, acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt][s], Bl[s], acc[mt], 0, 0, 0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt][s], bh, acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[mt][s], Bh[s], acc[mt], 0, 0, 0);
         }
-        const int t = tau + cx.tcol;
+    };
+    auto epi = [&](const f32x4 (&acc)[MT], int k, bool mask) { // tile k past the one the loop stands at
         if constexpr (L < 3) {
             float v[8]; // channels 8q + 4mt + r = slot j = 4mt + r of this lane's chunk
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[4 * mt + r] = relu_bits(acc[mt][r]);
-            if (tau + 16 > cx.T) { // only the tile that crosses the sequence end: frames >= T are padding
-                const bool inside = t < cx.T;
+            if (mask) { // frames >= T are the zero padding of the next layer
+                const bool inside = tq + 16 * k < cx.T;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = inside ? v[j] : 0.f;
             }
             f16x8 oh, ol;
             split8(v, oh, ol);
-            *reinterpret_cast<f16x8*>(img_h + woff) = oh;
-            *reinterpret_cast<f16x8*>(img_l + woff) = ol;
-            woff += 16 * 64;
+            *(lds_f16x8*)(wp + k * 1024) = oh;
+            *(lds_f16x8*)(wp + k * 1024 + kImg3) = ol;
         } else {
-            hs.store(cx, acc, m);
+            hs.store(cx, acc, k);
         }
+    };
+    auto fetch = [&](f16x8 (&Bh)[kTaps], f16x8 (&Bl)[kTaps], int k) { // unconditional, see kernel_mfma16.h
+#pragma unroll
+        for (int s = 0; s < kTaps; ++s) {
+            Bh[s] = *(lds_cf16x8*)(rp[s] + k * 1024);
+            Bl[s] = *(lds_cf16x8*)(rp[s] + k * 1024 + kImg3);
+        }
+    };
+    auto advance2 = [&]() {
+#pragma unroll
+        for (int s = 0; s < kTaps; ++s) {
+            rp[s] += 2048;
+            asm volatile("" : "+v"(rp[s]));
+        }
+        wp += 2048;
+        asm volatile("" : "+v"(wp));
+        tq += 32;
+        if constexpr (L == 3) hs.advance2();
+    };
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < 5 * MT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); // DS read
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); // VALU
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0); // VMEM write (head) ...
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); // ... or DS write
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+    };
+    f16x8 B0h[kTaps], B0l[kTaps], B1h[kTaps], B1l[kTaps];
+    f32x4 accA[MT], accB[MT];
+    fetch(B0h, B0l, 0);
+    fetch(B1h, B1l, 1);
+    mma(accA, B0h, B0l); // tile 0
+    fetch(B0h, B0l, 2);
+    int m = 1; // the pointers stand at tile m - 1
+#pragma unroll 1
+    for (; m + 1 < ntiles; m += 2) {
+        mma(accB, B1h, B1l); epi(accA, 0, false); fetch(B1h, B1l, 3); interleave();
+        mma(accA, B0h, B0l); epi(accB, 1, false); fetch(B0h, B0l, 4); interleave();
+        advance2();
     }
+    if (m < ntiles) { mma(accB, B1h, B1l); epi(accA, 0, false); epi(accB, 1, true); }
+    else epi(accA, 0, true);
     B2H_STAMP3(cx, 3 + 2 * L); // tiles done
     if constexpr (L < 3) {
+        char* img_h = cx.lds;
+        char* img_l = cx.lds + kImg3;
         if (hi == cx.T) { // rows T, T+1 of the next layer's input: zero unless a tile covered them
             const int covered = lo + 16 * ntiles;
             const int t = cx.T + ((cx.lane >> 2) & 1);
@@ -212,6 +266,7 @@ __device__ __forceinline__ void stage_input3(const ChunkCtx& cx, const float* __
 
 // One wave per (sequence, chunk); no workgroup barrier anywhere.
 // (two 4-wave workgroups per CU by LDS: 2 waves per SIMD, so each may use 256 VGPRs)
+template <bool FUSED>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma_f16x3(
     const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq, int chunk_len,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
@@ -237,7 +292,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma_f16x3(
     B2H_STAMP3(cx, 0);
     stage_input3(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
     B2H_STAMP3(cx, 1); // input staged
-    layer3<0>(cx, mp); layer3<1>(cx, mp); layer3<2>(cx, mp); layer3<3>(cx, mp);
+    layer3<0, FUSED>(cx, mp); layer3<1, FUSED>(cx, mp); layer3<2, FUSED>(cx, mp); layer3<3, FUSED>(cx, mp);
 }
 
 } // namespace b2h

@@ -160,7 +160,7 @@ def test_wide_models_vs_oracle(C, prec, cuda_device):
     for pos_emb, lengths in ((False, [1, 5, 16, 17, 50, 111, 112, 113, 200, 225, 337]), (True, [100])):
         m = hps.ConvModel(C, "ReLU", pos_emb, precision=prec).to(cuda_device).eval()
         state = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
-        assert m.kernel_name() == {"bf16": "b2h_fwd_mfma16w<1>", "f16": "b2h_fwd_mfma16w<2>", "f32_valu": "b2h_fwd_f32_valu"}[prec]
+        assert m.kernel_name() == {"bf16": "b2h_fwd_mfma16w<1, false>", "f16": "b2h_fwd_mfma16w<2, false>", "f32_valu": "b2h_fwd_f32_valu"}[prec]
         g = torch.Generator().manual_seed(C)
         for T in lengths:
             x = torch.rand((4, T, 12, 2), generator=g) - 0.5
