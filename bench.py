@@ -356,9 +356,9 @@ def main():
         # (1) the bench shard, handed back piece by piece while the next piece computes
         Sg = args.gather_seqs or (S if backend == "nccl" else min(S, 2048))
         Sg = min(Sg, S)
-        if rank == 0:
+        if rank == 0:   # rank 0 holds the whole gathered stream (and, briefly, a piece in flight per peer)
             free, _tot = torch.cuda.mem_get_info(dev)
-            while Sg > 1024 and world * Sg * T * 168 * 1.15 > free:
+            while Sg > 1024 and world * Sg * T * 168 * 1.25 > free:
                 Sg //= 2
         sg_t = torch.tensor([Sg], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
         dist.broadcast(sg_t, 0)
@@ -368,7 +368,14 @@ def main():
         xs = x[:Sg]
         n_tot = Sg * world
         res = {}
-        t_incl = timed(lambda: res.__setitem__("y", stream.run_pipelined(xs, n_tot, chunk)), 3, 1)
+
+        def handed_back():          # the previous result is released before the next one is allocated
+            res.clear()
+            res["y"] = stream.run_pipelined(xs, n_tot, chunk)
+
+        t_incl = timed(handed_back, 3, 1)
+        if rank == 0 and tuple(res["y"].shape) != (n_tot, T, 21, 2):
+            sys.exit(f"[bench] gathered stream has shape {tuple(res['y'].shape)}, expected {(n_tot, T, 21, 2)}")
         res.clear()
         torch.cuda.empty_cache()
         t_excl = timed(lambda: [model.forward_into(xs[a:a + chunk], y[a:a + chunk]) for a in range(0, Sg, chunk)], 3, 1)

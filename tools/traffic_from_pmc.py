@@ -5,7 +5,11 @@ gfx950 corrections per MI355X_MICROARCH.md (HBM section): both counters are in K
 FETCH_SIZE reports exactly half the bytes of a wide coalesced streaming read (16 B/lane),
 so it is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
 
-    python tools/traffic_from_pmc.py gpurun_out/<tag> [kernel-substring] > profiles/<tag>/traffic.json
+    python tools/traffic_from_pmc.py gpurun_out/<tag> [kernel-substring] [seqs frames precision] > profiles/<tag>/traffic.json
+
+With the workload given, the record is stamped with it and with the sha256 of the kernel sources the
+passes ran on (bench.sources_sha256): bench.py reports the figure as `roofline.traffic` only while
+both still match, so an edit of the kernel leaves it null instead of silently stale.
 """
 import csv, glob, json, os, sys
 
@@ -27,4 +31,12 @@ out = {"kernel": want, "launches": min(n1, n2),
        "read_bytes": 2 * fetch_kib * 1024, "write_bytes": write_kib * 1024,
        "traffic_bytes": 2 * fetch_kib * 1024 + write_kib * 1024,
        "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads count 128-B requests as 64 B); WRITE_SIZE exact"}
+if len(sys.argv) > 5:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    seqs, frames, prec = int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    out.update(seqs_per_gpu=seqs, frames_per_seq=frames, precision=prec,
+               algorithmic_bytes=seqs * frames * bench.BYTES_PER_FRAME,
+               sources_sha256=bench.sources_sha256(), sources=bench.TRAFFIC_SOURCES,
+               command="tools/profile.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py")
 print(json.dumps(out, indent=1))
