@@ -74,6 +74,8 @@ def parse(argv=None):
                     help="sequences per GPU in the pipelined hand-back measurement (0 = the bench shard, "
                          "reduced to what fits rank 0's memory; 2048 under gloo)")
     ap.add_argument("--no-gather", action="store_true", help="skip the hand-back measurement (N > 1)")
+    ap.add_argument("--gather-budget", type=float, default=180.0,
+                    help="seconds the hand-back measurement may take before the line is printed without it")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even for one rank (smoke test of RCCL on a one-GPU box)")
     return ap.parse_args(argv)
@@ -337,7 +339,8 @@ def main():
         out["roofline"] = rf
 
     # ---- N > 1: the hand-back of the keypoints to rank 0, timed (never part of `value`) ----------
-    if world > 1 and not args.no_gather:
+    def gather_phase():
+        """The timed hand-back of the keypoints to rank 0 (never part of `value`); returns the `gather` object."""
         from hand_pose_sl_amd.stream import ShardedStream, shard_bounds
         stream = ShardedStream(model)
         gat = {"backend": "rccl" if backend == "nccl" else "gloo (rehearsal)",
@@ -397,7 +400,36 @@ def main():
                           "ms_incl": t4_incl * 1e3, "ms_excl": t4_excl * 1e3,
                           "frames_per_s_incl": n4 * T / t4_incl, "frames_per_s_excl": n4 * T / t4_excl,
                           "bytes_into_rank0": into0}
-        out["gather"] = gat
+        return gat
+
+    if world > 1 and not args.no_gather:
+        # `value` and the roofline above are already measured.  The hand-back is a SECONDARY figure:
+        # neither an RCCL error in it nor a hung peer may cost the run its line, so an exception is
+        # recorded in the object, and a watchdog (all ranks) ends a phase that outlives its budget --
+        # rank 0 printing the line first -- long before RCCL's own watchdog would abort the process.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["gather"] = {"error": f"hand-back measurement did not finish within {args.gather_budget:.0f} s; "
+                                          f"`value` / `roofline` were measured before it and stand"}
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            sys.stderr.write(f"[bench rank {rank}] gather phase exceeded {args.gather_budget:.0f} s: giving up on it\n")
+            os._exit(0)
+
+        dog = threading.Timer(args.gather_budget, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            out["gather"] = gather_phase()
+        except Exception as exc:  # noqa: BLE001 -- any failure of the secondary measurement
+            sys.stderr.write(f"[bench rank {rank}] gather phase failed: {type(exc).__name__}: {exc}\n")
+            out["gather"] = {"error": f"{type(exc).__name__}: {exc}"}
+            dog.cancel()
+            if rank == 0:
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os._exit(0)      # peers may be parked in a collective this rank will never join
+        dog.cancel()
 
     if rank == 0 and world == 1:
         # the same shard through every other precision of the path, graded the same way

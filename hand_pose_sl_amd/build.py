@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libb2h.so")
 SOURCES = ["b2h_api.hip"]
-HEADERS = [os.path.join("dev", "b2h_dev.h"), os.path.join("dev", "b2h_dev_exports.h"), "b2h_common.h", "kernel_mfma.h", "kernel_mfma16.h", "kernel_mfma16w.h", "kernel_mfma3.h", "kernel_tenc.h", "kernel_valu.h", os.path.join("..", "..", "include", "b2h.h")]
+HEADERS = [os.path.join("dev", "b2h_dev.h"), os.path.join("dev", "b2h_dev_exports.h"), "b2h_common.h", "kernel_mfma.h", "kernel_mfma16.h", "kernel_mfma16w.h", "kernel_mfma3.h", "kernel_mfma3w.h", "kernel_tenc.h", "kernel_valu.h", os.path.join("..", "..", "include", "b2h.h")]
 ARCH = "gfx950"
 
 

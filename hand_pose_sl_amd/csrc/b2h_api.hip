@@ -19,6 +19,7 @@
 #include "kernel_mfma16.h"
 #include "kernel_mfma16w.h"
 #include "kernel_mfma3.h"
+#include "kernel_mfma3w.h"
 #include "kernel_tenc.h"
 #include "kernel_valu.h"
 
@@ -128,9 +129,10 @@ struct b2h_model {
     DevBuf m3_w[4];               // f16x3 kernel: per-layer hi / lo f16 fragments (bias shared)
     DevBuf mbf16_all, mf16_all;   // persistent 16-bit kernel: [W L0..L3 | bias L0..L3], kPacked16 bytes
     DevBuf mwbf_w[4], mwh_w[4], mw_bias[4]; // wide 16-bit kernel (33..64 channels): bf16 / f16 fragments, bias
+    DevBuf mw3_w[4];                        // wide f16x3 kernel: hi / lo f16 fragments (bias shared)
     int num_cus = 256;
     ValuParams vp;
-    MfmaParams mp32, mp3, mpw_bf, mpw_h;
+    MfmaParams mp32, mp3, mpw_bf, mpw_h, mpw3;
     float w_absmax = 0.f;         // largest |weight| or |bias| (NaN counts as inf): F16X3 needs < 65504
 };
 
@@ -182,19 +184,34 @@ int pack_wide(b2h_model* m, const HostWeights& hw) {
                             wb[idx] = f32_to_bf16(v);
                             wh[idx] = f32_to_f16(v);
                         }
+        // f16x3: [mt][tap][ks][hi|lo][lane][8], w = hi + lo with hi = f16(w), lo = f16(w - hi)
+        std::vector<_Float16> w3((size_t)MT * kTaps * KS * 2 * 64 * 8);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int k = 0; k < kTaps; ++k)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const float v = hw.at(l, chan(mt, lane & 15), 32 * ks + 8 * (lane >> 4) + j, k, true);
+                            const _Float16 hi = (_Float16)v;
+                            const size_t at = (((((size_t)mt * kTaps + k) * KS + ks) * 2) * 64 + lane) * 8 + j;
+                            w3[at] = hi;
+                            w3[at + 64 * 8] = (_Float16)(v - (float)hi);
+                        }
         std::vector<float> bf((size_t)MT * 16);
         for (int mt = 0; mt < MT; ++mt)
             for (int q = 0; q < 4; ++q)
                 for (int r = 0; r < 4; ++r) bf[(mt * 4 + q) * 4 + r] = hw.bias(l, chan(mt, 4 * q + r));
         int rc;
+        if ((rc = m->mw3_w[l].upload(w3.data(), w3.size() * 2))) return rc;
+        m->mpw3.w[l] = m->mw3_w[l].p;
         if ((rc = m->mwbf_w[l].upload(wb.data(), wb.size() * 2))) return rc;
         if ((rc = m->mwh_w[l].upload(wh.data(), wh.size() * 2))) return rc;
         if ((rc = m->mw_bias[l].upload(bf.data(), bf.size() * 4))) return rc;
         m->mpw_bf.w[l] = m->mwbf_w[l].p;
         m->mpw_h.w[l] = m->mwh_w[l].p;
-        m->mpw_bf.bias[l] = m->mpw_h.bias[l] = (const float*)m->mw_bias[l].p;
+        m->mpw_bf.bias[l] = m->mpw_h.bias[l] = m->mpw3.bias[l] = (const float*)m->mw_bias[l].p;
     }
-    m->mpw_bf.pos_emb = m->mpw_h.pos_emb = m->pos_emb;
+    m->mpw_bf.pos_emb = m->mpw_h.pos_emb = m->mpw3.pos_emb = m->pos_emb;
     return B2H_OK;
 }
 
@@ -305,7 +322,7 @@ bool kernel_ok(const b2h_model* m, int k) {
         case B2H_KERNEL_F32_MFMA: return m->C <= kMfmaWidth;
         case B2H_KERNEL_BF16_MFMA:
         case B2H_KERNEL_F16_MFMA: return m->C <= kMaxWidth; // > 32 channels: the wide kernel
-        case B2H_KERNEL_F16X3_MFMA: return m->C <= kMfmaWidth && (!m->has_weights || m->w_absmax < kF16Max);
+        case B2H_KERNEL_F16X3_MFMA: return m->C <= kMaxWidth && (!m->has_weights || m->w_absmax < kF16Max);
         default: return false;
     }
 }
@@ -329,6 +346,7 @@ int set_conv_kernel_attributes() {
     if ((rc = raise_lds_cap(b2h_fwd_f32_valu<true>)) || (rc = raise_lds_cap(b2h_fwd_f32_valu<false>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma_f32<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f32<true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma_f16x3<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3<true>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma_f16x3w<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3w<true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_BF16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_BF16, true>)) ||
@@ -363,7 +381,7 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         return fail(B2H_ERR_INVALID, "B2H_POST_MASK_TAIL needs n_frames");
     const int k = resolve_kernel(m, kernel);
     if (!kernel_ok(m, k)) {
-        if (k == B2H_KERNEL_F16X3_MFMA && m->C <= kMfmaWidth)
+        if (k == B2H_KERNEL_F16X3_MFMA)
             return fail(B2H_ERR_UNSUPPORTED, "F16X3 kernel: a weight or bias is outside the f16 range (|w| >= 65504 or "
                                              "not finite); use the exact fp32 kernel");
         return fail(B2H_ERR_UNSUPPORTED, "kernel variant does not support conv_channels=" + std::to_string(m->C));
@@ -386,8 +404,9 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         // bit-identical frames.
         const bool wide = m->C > kMfmaWidth; // 33..64 channels: wave-per-chunk 16-bit kernel (kernel_mfma16w.h)
         int chunk_len = kChunk;
+        const bool wide3 = wide && k == B2H_KERNEL_F16X3_MFMA; // one 4-wave workgroup per CU
         if (wide || (k != B2H_KERNEL_BF16_MFMA && k != B2H_KERNEL_F16_MFMA)) {
-            const int64_t slots = (int64_t)m->num_cus * 2 * kWavesPerBlock;
+            const int64_t slots = (int64_t)m->num_cus * (wide3 ? 1 : 2) * kWavesPerBlock;
             for (int cand : {64, 32}) {
                 if (B * ((T + chunk_len - 1) / chunk_len) * 2 >= slots) break;
                 chunk_len = cand;
@@ -404,7 +423,10 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         if (fusedc) hipLaunchKernelGGL((KERN<true>), g, blk, LDS, st, x, y, (int)T, cps, chunk_len, nchunks, MP, fa);  \
         else hipLaunchKernelGGL((KERN<false>), g, blk, LDS, st, x, y, (int)T, cps, chunk_len, nchunks, MP, fa);        \
     } while (0)
-        if (wide) {
+        if (wide3) {
+            const size_t lds = (size_t)kWavesPerBlock * 2 * kImg3W;
+            B2H_LAUNCHC(b2h_fwd_mfma_f16x3w, lds, m->mpw3);
+        } else if (wide) {
             const size_t lds = (size_t)kWavesPerBlock * kImgW;
             if (k == B2H_KERNEL_BF16_MFMA) B2H_LAUNCHC(b2h_fwd_mfma16w_bf16, lds, m->mpw_bf);
             else B2H_LAUNCHC(b2h_fwd_mfma16w_f16, lds, m->mpw_h);
@@ -873,7 +895,7 @@ const char* b2h_kernel_name(const b2h_model* m, int kernel) {
         case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma_f32<false>";
         case B2H_KERNEL_BF16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<1, false>" : "b2h_fwd_mfma16<1, false>";
         case B2H_KERNEL_F16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<2, false>" : "b2h_fwd_mfma16<2, false>";
-        case B2H_KERNEL_F16X3_MFMA: return "b2h_fwd_mfma_f16x3<false>";
+        case B2H_KERNEL_F16X3_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma_f16x3w<false>" : "b2h_fwd_mfma_f16x3<false>";
         default: return "";
     }
 }

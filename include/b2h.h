@@ -47,7 +47,7 @@ typedef enum b2h_kernel {
     B2H_KERNEL_BF16_MFMA = 3, /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16); any
                                  conv_channels <= 64 (33..64: the wide kernel, two k-steps per tap) */
     B2H_KERNEL_F16_MFMA = 4,  /* fp16 operands, fp32 accumulate (v_mfma_f32_16x16x32_f16); <= 64 likewise */
-    B2H_KERNEL_F16X3_MFMA = 5 /* conv_channels <= 32.
+    B2H_KERNEL_F16X3_MFMA = 5 /* any conv_channels <= 64 (33..64: a one-wave-per-SIMD wide variant).
                                  fp32-grade: every operand split into f16 hi + lo, three f16 MFMAs per
                                  product (hi.hi + hi.lo + lo.hi), fp32 accumulate; needs |x| < 65504:
                                  a model with a weight outside that range is refused

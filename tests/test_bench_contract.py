@@ -78,6 +78,15 @@ def test_self_launch_two_ranks_rehearsal(cuda_device):
         assert g[part]["bytes_into_rank0"] > 0
     assert g["config4"]["bytes_into_rank0"] == 1000 * 200 * 168
     assert "cpu_baseline" not in d            # rank 0 at N = 1 only
+    # the hand-back is a secondary figure: if it outlives its budget the line is still printed, with
+    # `value` / `roofline` intact and the failure named in the `gather` object
+    r = subprocess.run(base + ["--backend", "gloo", "--gather-budget", "0.2"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[:2000]
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["value"] > 1e8 and d2["roofline"]["frac"] > 0 and "error" in d2["gather"]
 
 
 def test_bench_refuses_without_a_gpu():
