@@ -215,22 +215,67 @@ def array2open_pose(array, confidence=None):
     return [float(x) for x in flat]
 
 
-def replace_right_hand(frame_json, hand_xy):
-    """The frame dict with people[0].hand_right_keypoints_2d replaced by the prediction
-    (traintest.py:292-293); returns the same (mutated) dict."""
-    frame_json["people"][0]["hand_right_keypoints_2d"] = array2open_pose(hand_xy)
+# ---- the other two `--predict` choices of the reference's CLIs (run.py:56-60) -----------------------
+# right_index   : input = body (12) + right hand without its index finger (17 joints), target = joints 5..8
+# right_3fingers: input = right-hand joints 13..20 + joint 0 (9) + body (12), target = joints 1..12
+# (steps/utils.py:215-259).  The reference's ConvModel / TransformerEnc are built for 12 input and 21
+# output joints only (HandPoseModels.py:28,32; infer_utterance.py:99-101), so no model of this path
+# can consume these items, there as here; the item builders and the output writers are mirrored for the
+# wire format's sake.
+PREDICT_TARGET_JOINTS = {"right_hand": slice(0, 21), "right_index": slice(5, 9), "right_3fingers": slice(1, 13)}
+
+
+def build_item(body_kp, right_hand_kp, predict="right_hand"):
+    """(input_kp, target_kp) of BuildRightHandItem / BuildIndexItem / Build3fingerItem
+    (steps/utils.py:261-277, 215-236, 238-259) for (T, 12, 2) body and (T, 21, 2) right-hand arrays."""
+    body_kp, right_hand_kp = np.asarray(body_kp), np.asarray(right_hand_kp)
+    if predict == "right_hand":
+        return body_kp, right_hand_kp
+    if predict == "right_index":
+        noindex = np.concatenate([right_hand_kp[:, 0:5], right_hand_kp[:, 9:]], axis=1)
+        return np.concatenate([body_kp, noindex], axis=1), right_hand_kp[:, 5:9]
+    if predict == "right_3fingers":
+        no3 = np.concatenate([right_hand_kp[:, 13:], right_hand_kp[:, 0:1]], axis=1)
+        return np.concatenate([no3, body_kp], axis=1), right_hand_kp[:, 1:13]
+    raise ValueError(f"predict must be one of {sorted(PREDICT_TARGET_JOINTS)}")
+
+
+def array2open_pose_part(openpose_right_hand, predicted, predict):
+    """array2open_pose_index / array2open_pose_3finger (steps/utils.py:341-353, 366-381): the flat
+    63-float right-hand list with the predicted joints (4 x 2 or 12 x 2, confidence 1.0) written over
+    joints 5..8 or 1..12; mutates and returns the list like the reference."""
+    sl = PREDICT_TARGET_JOINTS[predict]
+    n = sl.stop - sl.start
+    predicted = np.asarray(predicted)
+    flat = np.reshape(np.concatenate((predicted, np.zeros((n, 1)) + 1.0), axis=1), (-1))
+    flat = [float(x) for x in flat]
+    assert len(flat) == n * 3
+    openpose_right_hand[sl.start * 3:sl.stop * 3] = flat
+    return openpose_right_hand
+
+
+def replace_right_hand(frame_json, hand_xy, predict="right_hand"):
+    """The frame dict with people[0].hand_right_keypoints_2d replaced by the prediction -- the whole
+    hand, or only the predicted finger joints for `right_index` / `right_3fingers`
+    (traintest.py:281-293); returns the same (mutated) dict."""
+    person = frame_json["people"][0]
+    if predict == "right_hand":
+        person["hand_right_keypoints_2d"] = array2open_pose(hand_xy)
+    else:
+        person["hand_right_keypoints_2d"] = array2open_pose_part(person["hand_right_keypoints_2d"], hand_xy, predict)
     return frame_json
 
 
-def write_predictions(frames, prediction, output_folder):
+def write_predictions(frames, prediction, output_folder, predict="right_hand"):
     """Re-dump every frame file with its predicted right hand (traintest.py:274-300).
-    `frames`: the utterance's frame paths; `prediction`: (>= len(frames), 21, 2) in pixels."""
+    `frames`: the utterance's frame paths; `prediction`: (>= len(frames), J, 2) in pixels with J = 21,
+    4 (`right_index`) or 12 (`right_3fingers`)."""
     os.makedirs(output_folder, exist_ok=True)
     written = []
     for i, path in enumerate(frames):
         with open(path) as f:
             data = json.load(f)
-        replace_right_hand(data, prediction[i])
+        replace_right_hand(data, prediction[i], predict)
         out = os.path.join(output_folder, os.path.basename(path))
         with open(out, "w") as f:
             json.dump(data, f)

@@ -286,6 +286,31 @@ def wire_formats_case(tpd, tt, name, seed):
     print(f"{name}: merged {len(merged)} frames, h5 row {row.shape}, h5 writer {rec['h5w_out'].shape}")
 
 
+def predict_variants_case(utils, name, seed):
+    """The other two `--predict` choices (run.py:56-60): the reference's item builders
+    BuildIndexItem / Build3fingerItem (steps/utils.py:215-259) and output writers
+    array2open_pose_index / array2open_pose_3finger (steps/utils.py:341-353, 366-381) on synthetic data."""
+    import json
+    gen = torch.Generator().manual_seed(seed)
+    T = 7
+    body = torch.rand((T, 12, 2), generator=gen) * torch.tensor([1280.0, 720.0])
+    rhand = torch.rand((T, 21, 2), generator=gen) * torch.tensor([1280.0, 720.0])
+    rec = {"body": body.numpy(), "right_hand": rhand.numpy()}
+    for tag, cls in (("right_index", utils.BuildIndexItem), ("right_3fingers", utils.Build3fingerItem)):
+        item = cls()({"body_kp": body.clone(), "right_hand_kp": rhand.clone()})
+        rec[tag + "_input_kp"] = item["input_kp"].numpy()
+        rec[tag + "_target_kp"] = item["target_kp"].numpy()
+    rng = np.random.default_rng(seed)
+    hand_list = [float(round(v, 3)) for v in rng.uniform(0, 1280, 63)]
+    pred4 = rng.uniform(0, 1280, (4, 2)).astype(np.float32)
+    pred12 = rng.uniform(0, 1280, (12, 2)).astype(np.float32)
+    rec.update(hand_list=np.array(hand_list), pred4=pred4, pred12=pred12,
+               out_index=np.array(utils.array2open_pose_index(list(hand_list), pred4)),
+               out_3finger=np.array(utils.array2open_pose_3finger(list(hand_list), pred12)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: index input {rec['right_index_input_kp'].shape}, 3finger input {rec['right_3fingers_input_kp'].shape}")
+
+
 def _load_traintest(utils):
     """steps/traintest.py imports its siblings relatively (`from .utils import ...`): give it an
     in-memory parent package whose `utils` is the module already loaded from steps/utils.py."""
@@ -340,6 +365,8 @@ def main():
     openpose_case(tpd, utils, hpm, "openpose_long_n30_m20", 30, 20, 22)
     # merged JSON + HDF5 row
     wire_formats_case(tpd, _load_traintest(utils), "wire_formats", 23)
+    # --predict right_index / right_3fingers item builders and writers
+    predict_variants_case(utils, "predict_variants", 29)
 
 
 if __name__ == "__main__":

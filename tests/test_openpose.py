@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from hand_pose_sl_amd import openpose
-from conftest import load_golden
+from conftest import GOLDEN, load_golden
 
 CASES = ["openpose_short_n7_m12", "openpose_long_n30_m20"]
 
@@ -229,3 +229,32 @@ def test_h5_row_codec_equals_reference():
     except ImportError:
         with pytest.raises(RuntimeError, match="h5py"):
             openpose.read_h5_utterance("nope.h5", "utt")
+
+
+def test_predict_variants_match_reference(tmp_path):
+    """`--predict right_index | right_3fingers` (run.py:56-60): item builders and output writers against
+    vectors from the reference's BuildIndexItem / Build3fingerItem / array2open_pose_index /
+    array2open_pose_3finger (tests/golden/make_golden.py:predict_variants_case)."""
+    import json
+    d = np.load(os.path.join(GOLDEN, "predict_variants.npz"))
+    for tag in ("right_index", "right_3fingers"):
+        inp, tgt = openpose.build_item(d["body"], d["right_hand"], tag)
+        assert np.array_equal(inp, d[tag + "_input_kp"]) and np.array_equal(tgt, d[tag + "_target_kp"])
+    inp, tgt = openpose.build_item(d["body"], d["right_hand"])
+    assert np.array_equal(inp, d["body"]) and np.array_equal(tgt, d["right_hand"])
+    hand = [float(v) for v in d["hand_list"]]
+    assert openpose.array2open_pose_part(list(hand), d["pred4"], "right_index") == [float(v) for v in d["out_index"]]
+    assert openpose.array2open_pose_part(list(hand), d["pred12"], "right_3fingers") == [float(v) for v in d["out_3finger"]]
+    with pytest.raises(ValueError):
+        openpose.build_item(d["body"], d["right_hand"], "left_hand")
+    # through the frame writer: only joints 5..8 change, the rest of the frame is kept
+    frame = {"version": 1.3, "people": [{"pose_keypoints_2d": [0.0] * 75, "hand_left_keypoints_2d": [1.0] * 63,
+                                         "hand_right_keypoints_2d": list(hand)}]}
+    src = tmp_path / "in"
+    src.mkdir()
+    path = src / "f_000000000000_keypoints.json"
+    path.write_text(json.dumps(frame))
+    out = openpose.write_predictions([str(path)], d["pred4"][None], str(tmp_path / "out"), predict="right_index")
+    got = json.load(open(out[0]))["people"][0]
+    assert got["hand_right_keypoints_2d"] == [float(v) for v in d["out_index"]]
+    assert got["hand_left_keypoints_2d"] == [1.0] * 63
