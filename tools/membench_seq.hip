@@ -21,7 +21,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, int bytes)
 // PAT 0: output stores lane-linear (33 x 1 KiB per sequence); PAT 1: the kernel's head pattern
 // (per 16-frame tile three 16-B stores per lane: 16 rows x 64-B segments at a 168-B stride).
 // ADJ 1: the W waves of a workgroup take W adjacent sequences; ADJ 0: sequences strided by the grid.
-template <int MODE, int PAT, int ADJ>
+// SAUX / LAUX: cache-policy bits of the stores / loads (0 default, 1 sc0, 2 nt, 16 sc1, 17 sc0 sc1).
+template <int MODE, int PAT, int ADJ, int SAUX = 0, int LAUX = 0>
 __global__ void k_seq(const char* __restrict__ x, char* __restrict__ y, int nseq, unsigned* sink) {
     const int W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -33,7 +34,7 @@ __global__ void k_seq(const char* __restrict__ x, char* __restrict__ y, int nseq
         if (MODE & 1) {
             const __amdgpu_buffer_rsrc_t rs = rsrc(x + (size_t)seq * XB, XB);
 #pragma unroll
-            for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0);
+            for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, LAUX);
 #pragma unroll
             for (int j = 0; j < 19; ++j) acc += v[j][0] ^ v[j][3];
         }
@@ -42,16 +43,16 @@ __global__ void k_seq(const char* __restrict__ x, char* __restrict__ y, int nseq
             const u32x4 d = {acc, 2u, 3u, (unsigned)seq};
             if (PAT == 0) {
 #pragma unroll
-                for (int j = 0; j < 33; ++j) __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, 0);
+                for (int j = 0; j < 33; ++j) __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, SAUX);
             } else {
                 const int tcol = lane & 15, q = lane >> 4;
                 const int off = tcol * 168 + 16 * q;
 #pragma unroll
                 for (int m = 0; m < 13; ++m) {
-                    __builtin_amdgcn_raw_buffer_store_b128(d, ws, off, m * 2688, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(d, ws, off, m * 2688 + 64, 0);
-                    if (q < 2) __builtin_amdgcn_raw_buffer_store_b128(d, ws, off, m * 2688 + 128, 0);
-                    else if (q == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{acc, 1u}, ws, off, m * 2688 + 128, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, ws, off, m * 2688, SAUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(d, ws, off, m * 2688 + 64, SAUX);
+                    if (q < 2) __builtin_amdgcn_raw_buffer_store_b128(d, ws, off, m * 2688 + 128, SAUX);
+                    else if (q == 2) __builtin_amdgcn_raw_buffer_store_b64(u32x2{acc, 1u}, ws, off, m * 2688 + 128, SAUX);
                 }
             }
         }
@@ -94,6 +95,16 @@ int main(int argc, char** argv) {
         run("mixed seq linear", W, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 0, 0>), g, b, 0, 0, x, y, nseq, sink); });
         run("mixed seq head-pattern", W, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0>), g, b, 0, 0, x, y, nseq, sink); });
         run("mixed seq head-pattern, adjacent waves", W, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 1>), g, b, 0, 0, x, y, nseq, sink); });
+    }
+    {   // cache policies on the kernel's own shape (8 waves per CU, head-pattern stores)
+        const dim3 g(256), b(64 * 8);
+        run("mixed head-pattern, stores sc0", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 1, 0>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed head-pattern, stores sc1", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 16, 0>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed head-pattern, stores sc0 sc1", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 17, 0>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed head-pattern, loads nt", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 0, 2>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed head-pattern, loads sc1", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 0, 16>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed head-pattern, loads nt + stores sc1", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 16, 2>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed linear, loads nt", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 0, 0, 0, 2>), g, b, 0, 0, x, y, nseq, sink); });
     }
     for (int W : {1, 4, 8}) {
         const dim3 g(256), b(64 * W);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: randomized sweep of the TransformerEnc path against the numpy oracle -- random batch,
-length (1..100), layer count, weight scale and kernel (fp32 / f16x3); plus the masked-L1 metric
+length (1..100), layer count, weight scale, kernel (fp32 / f16x3) and, for a third of the cases, the
+fused item transforms with random flags and ragged tail masks; plus the masked-L1 metric
 and the target transform (bit-exact) on random shapes.    python tools/stress_tenc.py [seconds=120] [seed=0]"""
 import os, sys, time
 import numpy as np, torch
@@ -29,19 +30,35 @@ while time.time() < t_end:
     m, state = models[key]
     T = int(rng.integers(1, 101))
     B = int(rng.choice([1, 2, 3, rng.integers(4, 24)]))
-    x = ((rng.random((B, T, 12, 2), dtype=np.float32) - 0.5) * float(rng.choice([1.0, 1.0, 3.0])))
-    with torch.no_grad():
-        y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
-    ref = oracle.transformer_forward(x, state)
+    fused = rng.random() < 0.35
+    if fused:   # raw pixels in, (masked) pixels out: transforms inside the chain kernel
+        body = (rng.random((B, T, 12, 2), dtype=np.float32) * np.array([1280.0, 720.0], np.float32))
+        nf = rng.integers(0, T + 1, B)
+        dif, norm, den, mask = (bool(rng.random() < 0.7) for _ in range(4))
+        with torch.no_grad():
+            y = m.forward_fused(torch.from_numpy(body).to(dev), n_frames=nf if mask else None, dif_encoding=dif,
+                                normalize=norm, denormalize=den, mask_tail=mask).cpu().numpy()
+        x, _ = oracle.preprocess(body, None, dif_encoding=dif, normalize=norm)
+        ref0 = oracle.transformer_forward(x, state)
+        ref = oracle.postprocess(ref0, 1280.0 if den else 1.0, nf if mask else None)
+        scale = (1280.0 if den else 1.0) * max(1.0, float(np.abs(ref0).max()))
+        if not norm:   # raw pixels (|x| up to 1280) straight into pose2hidden_projection: fp32 summation-order
+            scale *= 4.0   # noise of the 24-term products is ~1e-4 absolute before the first LayerNorm (measured 1.01x the unit bar)
+    else:
+        x = ((rng.random((B, T, 12, 2), dtype=np.float32) - 0.5) * float(rng.choice([1.0, 1.0, 3.0])))
+        with torch.no_grad():
+            y = m(torch.from_numpy(x).to(dev)).cpu().numpy()
+        ref = oracle.transformer_forward(x, state)
+        scale = max(1.0, float(np.abs(ref).max()))
     err = float(np.abs(y - ref).max())
     # fp32: the tests' 2e-5 bar.  f16x3: the same bar holds on reference-scale weights (fixed tests);
     # with weights scaled up to 1.8x per tensor here its error reached 0.95 of it in 12 485 cases, so
     # the sweep gives it 2x headroom -- it is looking for structural errors, which are O(0.1)
-    tol = (2e-5 if prec == "fp32" else 4e-5) * max(1.0, float(np.abs(ref).max()))
+    tol = (2e-5 if prec == "fp32" else 4e-5) * scale
     worst[prec] = max(worst[prec], err / tol)
     n += 1
     if not (err <= tol) or not np.isfinite(y).all():
-        print(f"FAIL case {n}: prec={prec} L={L} B={B} T={T} err={err:.3e} tol={tol:.3e}")
+        print(f"FAIL case {n}: prec={prec} L={L} B={B} T={T} fused={fused} err={err:.3e} tol={tol:.3e}")
         sys.exit(1)
     if n % 10 == 0:                                           # metric + target transform on the side
         Bm, Tm = int(rng.integers(1, 40)), int(rng.integers(1, 300))
