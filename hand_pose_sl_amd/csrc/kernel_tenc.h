@@ -348,14 +348,20 @@ __device__ __forceinline__ void chain_gemm(const f32x4* __restrict__ wl, int lan
 // 32-wide k-group g holds feature 32g + 16(j>>2) + 4q + (j&3), i.e. lane (frame, q) packs its own
 // accumulator tiles 2g (j < 4) and 2g+1 (j >= 4); the host packs the weights in the same slot order.
 __device__ __forceinline__ void chain_split(const f32x4 (&v)[8], f16x8 (&bh)[4], f16x8 (&bl)[4]) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = v[2 * g + (j >> 2)][j & 3];
-            const _Float16 hi = (_Float16)x;
-            bh[g][j] = hi;
-            bl[g][j] = (_Float16)(x - (float)hi);
+        for (int j = 0; j < 8; j += 2) { // two values per packed convert; residual = one v_fma_mix_f32 each
+            const float x0 = v[2 * g + (j >> 2)][j & 3], x1 = v[2 * g + (j >> 2)][(j & 3) + 1];
+            const f16x2 h = f16x2{(_Float16)x0, (_Float16)x1};
+            const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+            float r0, r1; // x - hi, exact in fp32 (asm: hipcc otherwise converts hi back and subtracts)
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(x0));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(x1));
+            const f16x2 l = f16x2{(_Float16)r0, (_Float16)r1};
+            bh[g][j] = h[0]; bh[g][j + 1] = h[1];
+            bl[g][j] = l[0]; bl[g][j + 1] = l[1];
         }
 }
 
@@ -549,14 +555,19 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
             const bool on = st.out != nullptr && !(B2H_ABLATE & 4096);
             const __amdgpu_buffer_rsrc_t ors = make_rsrc(on ? st.out + n0 * st.ldo : nullptr, on ? rows * st.ldo * 4 : 0);
             const bool raw = st.type == ST_STORE;
-            const bool head = post && raw && st.nout == kOutCh; // wave-uniform
+            if (post && raw && st.nout == kOutCh) { // wave-uniform: the output head of a fused forward only
+                // (a real branch: the empty asm keeps hipcc from if-converting it into ~80 selects and
+                // multiplies that every stage of every launch would then execute)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int m = 0; m < 3; ++m) { // the 42 outputs live in M-tiles 0..2
+                    acc[m] = acc[m] * omul;                 // x factor, or x 1.0f (exact)
+                    if (odead) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                f32x4 v = raw ? acc[m] : cur[m];
-                if (head) {
-                    v = v * omul;                       // x factor, or x 1.0f (exact)
-                    if (odead) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                const f32x4 v = raw ? acc[m] : cur[m];
                 const int o0 = 16 * m + 4 * q;
                 const uint32_t off = (uint32_t)(fr * st.ldo + o0) * 4u;
                 const bool whole = m < st.mtiles && o0 + 3 < st.nout;
