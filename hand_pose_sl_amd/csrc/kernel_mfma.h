@@ -23,6 +23,7 @@
 // with the swizzle, x2 / x4 without).
 #pragma once
 #include "b2h_common.h"
+#include "dev/b2h_dev.h" // B2H_ABLATE hooks: constant-false in the shipped build
 
 namespace b2h {
 
@@ -123,6 +124,85 @@ template <bool FUSED> struct HeadStore {
     }
 };
 
+// ---- pieces shared by the wave-per-chunk kernels (this file, kernel_mfma3.h, kernel_mfma16w.h,
+// kernel_mfma3w.h) ---------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() { // one wave's LDS writes visible to its own later reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// This wave's chunk: one wave per (sequence, chunk), `lds_per_wave` bytes of the workgroup's dynamic LDS
+// each.  False when the wave has no chunk (tail of the grid).
+__device__ __forceinline__ bool chunk_ctx(ChunkCtx& cx, char* smem, int lds_per_wave, float* __restrict__ y, int T,
+                                          int chunks_per_seq, int chunk_len, int64_t nchunks, const FusedArgs& fa) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (chunk >= nchunks) return false;
+    cx.lds = smem + (size_t)wave * lds_per_wave;
+    cx.lane = threadIdx.x & 63;
+    cx.tcol = cx.lane & 15;
+    cx.q = cx.lane >> 4;
+    cx.T = T;
+    cx.seq = chunk / chunks_per_seq;
+    const int c = (int)(chunk - cx.seq * chunks_per_seq);
+    cx.s = c * chunk_len; // <= kChunk frames (the LDS image's capacity); shorter when the batch is small
+    cx.e = min(cx.s + chunk_len, T);
+    cx.y = y + cx.seq * (int64_t)T * kOutCh;
+    cx.fa = fa;
+    cx.nvalid = T;
+    if ((fa.flags & kPostMask) && fa.n_frames) cx.nvalid = fa.n_frames[cx.seq];
+    return true;
+}
+
+// Input staging: the chunk's rows [s - 8, e + 8) clipped to the sequence, (T,24) fp32, as coalesced
+// float4 loads (8 in flight per lane: serial load->use exposes the HBM latency once per float4), the
+// reference's item transforms applied when fused, each float4 handed to put(P, c4, w) with P = its
+// physical LDS row (P(t,0) = t - s + 8) and c4 its float4 column (channels 4c4 .. 4c4+3); then
+// pad(P, pe) once per row for in-positions 24..31 (pos_emb: position 24 = t/100,
+// HandPoseModels.py:71-75; the layer-1 weights are packed with the position channel moved to slot 24).
+// Returns (first physical row, number of rows, whether the chunk ends at the sequence end).
+struct StagedRows { int P0, nrows; bool at_end; };
+template <typename PutF4, typename PutPad>
+__device__ __forceinline__ StagedRows stage_rows(const ChunkCtx& cx, const float* __restrict__ xs, int pos_emb,
+                                                 PutF4 put, PutPad pad) {
+    const int in_lo = max(cx.s - kHalo, 0), in_hi = min(cx.e + kHalo, cx.T);
+    const int pin = 8 - cx.s;
+    const int nf4 = (in_hi - in_lo) * (kInCh / 4);
+    const float4* src = reinterpret_cast<const float4*>(xs + (int64_t)in_lo * kInCh);
+    for (int i0 = cx.lane; i0 < nf4; i0 += 64 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u;
+            v[u] = (i < nf4 && !(B2H_ABLATE & 128)) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 64 * u;
+            if (i >= nf4) continue;
+            const int rr = i / 6, c4 = i - rr * 6;
+            const int t = in_lo + rr;
+            float4 w = v[u];
+            if (cx.fa.flags & kPreChest) { // body -= body[:,1]  (steps/utils.py:203-210)
+                const float2 ch = *reinterpret_cast<const float2*>(xs + (int64_t)t * kInCh + 2);
+                w.x -= ch.x; w.y -= ch.y; w.z -= ch.x; w.w -= ch.y;
+            }
+            if (cx.fa.flags & kPreNorm) { // body / factor     (steps/utils.py:180-190)
+                w.x = w.x / cx.fa.factor; w.y = w.y / cx.fa.factor;
+                w.z = w.z / cx.fa.factor; w.w = w.w / cx.fa.factor;
+            }
+            put(t + pin, c4, w);
+        }
+    }
+    const int nrows = in_hi - in_lo;
+    for (int r = cx.lane; r < nrows; r += 64) {
+        const int t = in_lo + r;
+        pad(t + pin, pos_emb ? (float)t / 100.0f : 0.f);
+    }
+    return StagedRows{in_lo + pin, nrows, in_hi == cx.T};
+}
+
 // ---- exact-fp32 layers (v_mfma_f32_16x16x4_f32) -------------------------------
 template <int L, bool FUSED>
 __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp) {
@@ -200,65 +280,25 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
             if (cx.lane < 16 && t >= covered)
                 *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(t + pout, cx.lane & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_lds_sync();
     }
 }
 
 // ---- input staging: (T,24) fp32 rows -> LDS image of layer-1 input ------------
 __device__ __forceinline__ void stage_input32(const ChunkCtx& cx, const float* __restrict__ xs, int pos_emb) {
-    const int in_lo = max(cx.s - kHalo, 0), in_hi = min(cx.e + kHalo, cx.T);
-    const int pin = 8 - cx.s; // P(t,0) = t + pin
-    const int nf4 = (in_hi - in_lo) * (kInCh / 4);
-    const float4* src = reinterpret_cast<const float4*>(xs + (int64_t)in_lo * kInCh);
-    // batches of 8 loads in flight per lane (serial load->use per iteration exposes the HBM
-    // latency once per float4)
-    for (int i0 = cx.lane; i0 < nf4; i0 += 64 * 8) {
-        float4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 64 * u;
-            v[u] = (i < nf4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 64 * u;
-            if (i >= nf4) continue;
-            const int rr = i / 6, c4 = i - rr * 6;
-            const int t = in_lo + rr;
-            float4 w = v[u];
-            if (cx.fa.flags & kPreChest) { // body -= body[:,1]  (steps/utils.py:203-210)
-                const float2 ch = *reinterpret_cast<const float2*>(xs + (int64_t)t * kInCh + 2);
-                w.x -= ch.x; w.y -= ch.y; w.z -= ch.x; w.w -= ch.y;
-            }
-            if (cx.fa.flags & kPreNorm) { // body / factor     (steps/utils.py:180-190)
-                w.x = w.x / cx.fa.factor; w.y = w.y / cx.fa.factor;
-                w.z = w.z / cx.fa.factor; w.w = w.w / cx.fa.factor;
-            }
-            *reinterpret_cast<float4*>(cx.lds + lds_off<128>(t + pin, c4)) = w;
-        }
-    }
-    // channel padding 24..31 (pos_emb: channel 24 = t/100, HandPoseModels.py:71-75;
-    // the layer-1 weights are packed with the position channel moved to slot 24)
-    const int nrows = in_hi - in_lo;
-    for (int r = cx.lane; r < nrows; r += 64) {
-        const int t = in_lo + r, Pr = t + pin;
-        const float pe = pos_emb ? (float)t / 100.0f : 0.f;
-        *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(Pr, 6)) = f32x4{pe, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(Pr, 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // zero rows: t in [-8,0) at the sequence start (all layers' low padding) and
-    // t = T, T+1 at the sequence end
-    if (cx.s == 0)
-        for (int i = cx.lane; i < 8 * 8; i += 64)
-            *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(i / 8, i % 8)) = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (in_hi == cx.T)
-        for (int i = cx.lane; i < 2 * 8; i += 64)
-            *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(cx.T + i / 8 + pin, i % 8)) = f32x4{0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const StagedRows st = stage_rows(
+        cx, xs, pos_emb,
+        [&](int P, int c4, float4 w) { *reinterpret_cast<float4*>(cx.lds + lds_off<128>(P, c4)) = w; },
+        [&](int P, float pe) { // channel padding 24..31 = chunks 6, 7
+            *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(P, 6)) = f32x4{pe, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(P, 7)) = z4;
+        });
+    // zero rows: t in [-8,0) at the sequence start (all layers' low padding) and t = T, T+1 at its end
+    if (cx.s == 0) *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(cx.lane >> 3, cx.lane & 7)) = z4;
+    if (st.at_end && cx.lane < 16)
+        *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(st.P0 + st.nrows + (cx.lane >> 3), cx.lane & 7)) = z4;
+    wave_lds_sync();
 }
 
 // One wave per (sequence, chunk); no workgroup barrier anywhere.  Two 4-wave workgroups per CU by
@@ -268,24 +308,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma_f32(
     const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq, int chunk_len,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem_mfma[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-    if (chunk >= nchunks) return;
-
     ChunkCtx cx;
-    cx.lds = smem_mfma + (size_t)wave * kRows * Prec<PREC_F32>::kRowBytes;
-    cx.lane = threadIdx.x & 63;
-    cx.tcol = cx.lane & 15;
-    cx.q = cx.lane >> 4;
-    cx.T = T;
-    cx.seq = chunk / chunks_per_seq;
-    const int c = (int)(chunk - cx.seq * chunks_per_seq);
-    cx.s = c * chunk_len; // <= kChunk frames (the LDS image's capacity); shorter when the batch is small
-    cx.e = min(cx.s + chunk_len, T);
-    cx.y = y + cx.seq * (int64_t)T * kOutCh;
-    cx.fa = fa;
-    cx.nvalid = T;
-    if ((fa.flags & kPostMask) && fa.n_frames) cx.nvalid = fa.n_frames[cx.seq];
+    if (!chunk_ctx(cx, smem_mfma, kRows * Prec<PREC_F32>::kRowBytes, y, T, chunks_per_seq, chunk_len, nchunks, fa)) return;
     stage_input32(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
     layer32<0, FUSED>(cx, mp); layer32<1, FUSED>(cx, mp); layer32<2, FUSED>(cx, mp); layer32<3, FUSED>(cx, mp);
 }

@@ -183,85 +183,55 @@ __device__ __forceinline__ void layer3(const ChunkCtx& cx, const MfmaParams& mp)
                 *reinterpret_cast<f32x4*>((cx.lane < 8 ? img_h : img_l) + lds_off<64>(t + pout, cx.lane & 3)) =
                     f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_lds_sync();
     }
 }
 
 // ---- input staging: (T,24) fp32 rows -> hi / lo images of layer-1 input ------------------------
+__device__ __forceinline__ void split4(const float4& w, f16x4& hi, f16x4& lo) {
+    const float e[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 a = (_Float16)e[j];
+        hi[j] = a;
+        lo[j] = (_Float16)(e[j] - (float)a);
+    }
+}
+
 __device__ __forceinline__ void stage_input3(const ChunkCtx& cx, const float* __restrict__ xs, int pos_emb) {
     char* img_h = cx.lds;
     char* img_l = cx.lds + kImg3;
-    const int in_lo = max(cx.s - kHalo, 0), in_hi = min(cx.e + kHalo, cx.T);
-    const int pin = 8 - cx.s; // P(t,0) = t + pin
-    const int nf4 = (in_hi - in_lo) * (kInCh / 4);
-    const float4* src = reinterpret_cast<const float4*>(xs + (int64_t)in_lo * kInCh);
-    for (int i0 = cx.lane; i0 < nf4; i0 += 64 * 8) { // 8 loads in flight per lane
-        float4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 64 * u;
-            v[u] = (i < nf4 && !(B2H_ABLATE & 128)) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 64 * u;
-            if (i >= nf4) continue;
-            const int rr = i / 6, c4 = i - rr * 6;
-            const int t = in_lo + rr;
-            float4 w = v[u];
-            if (cx.fa.flags & kPreChest) { // body -= body[:,1]  (steps/utils.py:203-210)
-                const float2 ch = *reinterpret_cast<const float2*>(xs + (int64_t)t * kInCh + 2);
-                w.x -= ch.x; w.y -= ch.y; w.z -= ch.x; w.w -= ch.y;
-            }
-            if (cx.fa.flags & kPreNorm) { // body / factor     (steps/utils.py:180-190)
-                w.x = w.x / cx.fa.factor; w.y = w.y / cx.fa.factor;
-                w.z = w.z / cx.fa.factor; w.w = w.w / cx.fa.factor;
-            }
-            const float e[4] = {w.x, w.y, w.z, w.w};
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const StagedRows st = stage_rows(
+        cx, xs, pos_emb,
+        [&](int P, int c4, float4 w) { // channels 4c4 .. 4c4+3: half (c4 & 1) of 16-B chunk c4 >> 1
             f16x4 wh, wl;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const _Float16 a = (_Float16)e[j];
-                wh[j] = a;
-                wl[j] = (_Float16)(e[j] - (float)a);
-            }
-            // channels 4c4 .. 4c4+3: half (c4 & 1) of 16-B chunk c4 >> 1
-            const int off = lds_off<64>(t + pin, c4 >> 1) + (c4 & 1) * 8;
+            split4(w, wh, wl);
+            const int off = lds_off<64>(P, c4 >> 1) + (c4 & 1) * 8;
             *reinterpret_cast<f16x4*>(img_h + off) = wh;
             *reinterpret_cast<f16x4*>(img_l + off) = wl;
-        }
-    }
-    // channel padding 24..31 = chunk 3 (pos_emb: channel 24 = t/100, HandPoseModels.py:71-75;
-    // the layer-1 weights are packed with the position channel moved to slot 24)
-    const int nrows = in_hi - in_lo;
-    for (int r = cx.lane; r < nrows; r += 64) {
-        const int t = in_lo + r, off = lds_off<64>(t + pin, 3);
-        const float pe = pos_emb ? (float)t / 100.0f : 0.f;
-        const _Float16 ph = (_Float16)pe;
-        f16x8 zh, zl;
+        },
+        [&](int P, float pe) { // channel padding 24..31 = chunk 3
+            const _Float16 ph = (_Float16)pe;
+            f16x8 zh, zl;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { zh[j] = (_Float16)0.f; zl[j] = (_Float16)0.f; }
-        zh[0] = ph;
-        zl[0] = (_Float16)(pe - (float)ph);
-        *reinterpret_cast<f16x8*>(img_h + off) = zh;
-        *reinterpret_cast<f16x8*>(img_l + off) = zl;
+            for (int j = 0; j < 8; ++j) { zh[j] = (_Float16)0.f; zl[j] = (_Float16)0.f; }
+            zh[0] = ph;
+            zl[0] = (_Float16)(pe - (float)ph);
+            *reinterpret_cast<f16x8*>(img_h + lds_off<64>(P, 3)) = zh;
+            *reinterpret_cast<f16x8*>(img_l + lds_off<64>(P, 3)) = zl;
+        });
+    // zero rows: t in [-8,0) at the sequence start (all layers' low padding) and t = T, T+1 at its end;
+    // 4 chunks per row per image
+    if (cx.s == 0) { // 8 rows x 4 chunks x 2 images
+        const int i = cx.lane;
+        *reinterpret_cast<f32x4*>((i < 32 ? img_h : img_l) + lds_off<64>((i & 31) >> 2, i & 3)) = z4;
     }
-    // zero rows: t in [-8,0) at the sequence start (all layers' low padding) and t = T, T+1 at
-    // the sequence end; 4 chunks per row per image
-    if (cx.s == 0) {
-        const int i = cx.lane; // 8 rows x 4 chunks x 2 images
-        *reinterpret_cast<f32x4*>((i < 32 ? img_h : img_l) + lds_off<64>((i & 31) >> 2, i & 3)) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (st.at_end && cx.lane < 16) { // 2 rows x 4 chunks x 2 images
+        const int i = cx.lane;
+        *reinterpret_cast<f32x4*>((i < 8 ? img_h : img_l) + lds_off<64>(st.P0 + st.nrows + ((i & 7) >> 2), i & 3)) = z4;
     }
-    if (in_hi == cx.T && cx.lane < 16) {
-        const int i = cx.lane; // 2 rows x 4 chunks x 2 images
-        *reinterpret_cast<f32x4*>((i < 8 ? img_h : img_l) + lds_off<64>(cx.T + ((i & 7) >> 2) + pin, i & 3)) =
-            f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_sync();
 }
 
 // One wave per (sequence, chunk); no workgroup barrier anywhere.
@@ -271,24 +241,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma_f16x3(
     const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq, int chunk_len,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem_mfma3[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-    if (chunk >= nchunks) return;
-
     ChunkCtx cx;
-    cx.lds = smem_mfma3 + (size_t)wave * 2 * kImg3;
-    cx.lane = threadIdx.x & 63;
-    cx.tcol = cx.lane & 15;
-    cx.q = cx.lane >> 4;
-    cx.T = T;
-    cx.seq = chunk / chunks_per_seq;
-    const int c = (int)(chunk - cx.seq * chunks_per_seq);
-    cx.s = c * chunk_len; // <= kChunk frames (the LDS image's capacity); shorter when the batch is small
-    cx.e = min(cx.s + chunk_len, T);
-    cx.y = y + cx.seq * (int64_t)T * kOutCh;
-    cx.fa = fa;
-    cx.nvalid = T;
-    if ((fa.flags & kPostMask) && fa.n_frames) cx.nvalid = fa.n_frames[cx.seq];
+    if (!chunk_ctx(cx, smem_mfma3, 2 * kImg3, y, T, chunks_per_seq, chunk_len, nchunks, fa)) return;
     B2H_STAMP3(cx, 0);
     stage_input3(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
     B2H_STAMP3(cx, 1); // input staged

@@ -112,9 +112,7 @@ __device__ __forceinline__ void layer3w(const ChunkCtx& cx, const MfmaParams& mp
                 *reinterpret_cast<f32x4*>((cx.lane < 16 ? img_h : img_l) + lds_offw(t + pout, cx.lane & 7)) =
                     f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wave_lds_sync();
     }
 }
 
@@ -122,73 +120,35 @@ __device__ __forceinline__ void layer3w(const ChunkCtx& cx, const MfmaParams& mp
 __device__ __forceinline__ void stage_input3w(const ChunkCtx& cx, const float* __restrict__ xs, int pos_emb) {
     char* img_h = cx.lds;
     char* img_l = cx.lds + kImg3W;
-    const int in_lo = max(cx.s - kHalo, 0), in_hi = min(cx.e + kHalo, cx.T);
-    const int pin = 8 - cx.s; // P(t,0) = t + pin
-    const int nf4 = (in_hi - in_lo) * (kInCh / 4);
-    const float4* src = reinterpret_cast<const float4*>(xs + (int64_t)in_lo * kInCh);
-    for (int i0 = cx.lane; i0 < nf4; i0 += 64 * 8) { // 8 loads in flight per lane
-        float4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 64 * u;
-            v[u] = (i < nf4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 64 * u;
-            if (i >= nf4) continue;
-            const int rr = i / 6, c4 = i - rr * 6;
-            const int t = in_lo + rr;
-            float4 w = v[u];
-            if (cx.fa.flags & kPreChest) { // body -= body[:,1]  (steps/utils.py:203-210)
-                const float2 ch = *reinterpret_cast<const float2*>(xs + (int64_t)t * kInCh + 2);
-                w.x -= ch.x; w.y -= ch.y; w.z -= ch.x; w.w -= ch.y;
-            }
-            if (cx.fa.flags & kPreNorm) { // body / factor     (steps/utils.py:180-190)
-                w.x = w.x / cx.fa.factor; w.y = w.y / cx.fa.factor;
-                w.z = w.z / cx.fa.factor; w.w = w.w / cx.fa.factor;
-            }
-            const float e[4] = {w.x, w.y, w.z, w.w};
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const StagedRows st = stage_rows(
+        cx, xs, pos_emb,
+        [&](int P, int c4, float4 w) { // channels 4c4 .. 4c4+3: half (c4 & 1) of 16-B chunk c4 >> 1
             f16x4 wh, wl;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const _Float16 a = (_Float16)e[j];
-                wh[j] = a;
-                wl[j] = (_Float16)(e[j] - (float)a);
-            }
-            // channels 4c4 .. 4c4+3: half (c4 & 1) of 16-B chunk c4 >> 1
-            const int off = lds_offw(t + pin, c4 >> 1) + (c4 & 1) * 8;
+            split4(w, wh, wl);
+            const int off = lds_offw(P, c4 >> 1) + (c4 & 1) * 8;
             *reinterpret_cast<f16x4*>(img_h + off) = wh;
             *reinterpret_cast<f16x4*>(img_l + off) = wl;
-        }
-    }
-    // in-positions 24..31 = chunk 3 (pos_emb: position 24 = t/100, HandPoseModels.py:71-75; the layer-1
-    // weights are packed with the position channel moved to slot 24).  Layer 1 reads chunks 0..3 only.
-    const int nrows = in_hi - in_lo;
-    for (int r = cx.lane; r < nrows; r += 64) {
-        const int t = in_lo + r, off = lds_offw(t + pin, 3);
-        const float pe = pos_emb ? (float)t / 100.0f : 0.f;
-        const _Float16 ph = (_Float16)pe;
-        f16x8 zh, zl;
+        },
+        [&](int P, float pe) { // in-positions 24..31 = chunk 3; layer 1 reads chunks 0..3 only
+            const _Float16 ph = (_Float16)pe;
+            f16x8 zh, zl;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { zh[j] = (_Float16)0.f; zl[j] = (_Float16)0.f; }
-        zh[0] = ph;
-        zl[0] = (_Float16)(pe - (float)ph);
-        *reinterpret_cast<f16x8*>(img_h + off) = zh;
-        *reinterpret_cast<f16x8*>(img_l + off) = zl;
-    }
+            for (int j = 0; j < 8; ++j) { zh[j] = (_Float16)0.f; zl[j] = (_Float16)0.f; }
+            zh[0] = ph;
+            zl[0] = (_Float16)(pe - (float)ph);
+            *reinterpret_cast<f16x8*>(img_h + lds_offw(P, 3)) = zh;
+            *reinterpret_cast<f16x8*>(img_l + lds_offw(P, 3)) = zl;
+        });
     // zero rows (all 8 chunks of both images): t in [-8,0) at the sequence start (every layer's low
     // padding) and t = T, T+1 at the sequence end
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     if (cx.s == 0) {
         *reinterpret_cast<f32x4*>(img_h + lds_offw(cx.lane >> 3, cx.lane & 7)) = z4;
         *reinterpret_cast<f32x4*>(img_l + lds_offw(cx.lane >> 3, cx.lane & 7)) = z4;
     }
-    if (in_hi == cx.T && cx.lane < 32)
-        *reinterpret_cast<f32x4*>((cx.lane < 16 ? img_h : img_l) + lds_offw(cx.T + ((cx.lane >> 3) & 1) + pin, cx.lane & 7)) = z4;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (st.at_end && cx.lane < 32) // 2 rows x 8 chunks x 2 images
+        *reinterpret_cast<f32x4*>((cx.lane < 16 ? img_h : img_l) + lds_offw(st.P0 + st.nrows + ((cx.lane >> 3) & 1), cx.lane & 7)) = z4;
+    wave_lds_sync();
 }
 
 // One wave per (sequence, chunk); no workgroup barrier anywhere.  One 4-wave workgroup per CU.
@@ -197,24 +157,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 1) void b2h_fwd_mfma_f16x3w(
     const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq, int chunk_len,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem_mfma3w[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-    if (chunk >= nchunks) return;
-
     ChunkCtx cx;
-    cx.lds = smem_mfma3w + (size_t)wave * 2 * kImg3W;
-    cx.lane = threadIdx.x & 63;
-    cx.tcol = cx.lane & 15;
-    cx.q = cx.lane >> 4;
-    cx.T = T;
-    cx.seq = chunk / chunks_per_seq;
-    const int c = (int)(chunk - cx.seq * chunks_per_seq);
-    cx.s = c * chunk_len; // <= kChunk frames (the LDS image's capacity); shorter when the batch is small
-    cx.e = min(cx.s + chunk_len, T);
-    cx.y = y + cx.seq * (int64_t)T * kOutCh;
-    cx.fa = fa;
-    cx.nvalid = T;
-    if ((fa.flags & kPostMask) && fa.n_frames) cx.nvalid = fa.n_frames[cx.seq];
+    if (!chunk_ctx(cx, smem_mfma3w, 2 * kImg3W, y, T, chunks_per_seq, chunk_len, nchunks, fa)) return;
     stage_input3w(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
     layer3w<0, FUSED>(cx, mp); layer3w<1, FUSED>(cx, mp); layer3w<2, FUSED>(cx, mp); layer3w<3, FUSED>(cx, mp);
 }
