@@ -129,10 +129,10 @@ struct b2h_model {
     DevBuf m3_w[4];               // f16x3 kernel: per-layer hi / lo f16 fragments (bias shared)
     DevBuf mbf16_all, mf16_all;   // persistent 16-bit kernel: [W L0..L3 | bias L0..L3], kPacked16 bytes
     DevBuf mwbf_w[4], mwh_w[4], mw_bias[4]; // wide 16-bit kernel (33..64 channels): bf16 / f16 fragments, bias
-    DevBuf mw3_w[4];                        // wide f16x3 kernel: hi / lo f16 fragments (bias shared)
+    DevBuf mw3_w[4], mw32_w[4];             // wide f16x3 kernel: hi / lo f16 fragments; wide exact-fp32 kernel: fp32 fragments
     int num_cus = 256;
     ValuParams vp;
-    MfmaParams mp32, mp3, mpw_bf, mpw_h, mpw3;
+    MfmaParams mp32, mp3, mpw_bf, mpw_h, mpw3, mpw32;
     float w_absmax = 0.f;         // largest |weight| or |bias| (NaN counts as inf): F16X3 needs < 65504
 };
 
@@ -197,11 +197,23 @@ int pack_wide(b2h_model* m, const HostWeights& hw) {
                             w3[at] = hi;
                             w3[at + 64 * 8] = (_Float16)(v - (float)hi);
                         }
+        // exact fp32: [mt][tap][g][lane][4], in-position 16g + 4(lane>>4) + j, groups as Geo32<true>
+        const int NG = Geo32<true>::groups(l);
+        std::vector<float> wf((size_t)MT * kTaps * NG * 64 * 4);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int k = 0; k < kTaps; ++k)
+                for (int g = 0; g < NG; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j)
+                            wf[((((size_t)mt * kTaps + k) * NG + g) * 64 + lane) * 4 + j] =
+                                hw.at(l, chan(mt, lane & 15), 16 * g + 4 * (lane >> 4) + j, k, true);
         std::vector<float> bf((size_t)MT * 16);
         for (int mt = 0; mt < MT; ++mt)
             for (int q = 0; q < 4; ++q)
                 for (int r = 0; r < 4; ++r) bf[(mt * 4 + q) * 4 + r] = hw.bias(l, chan(mt, 4 * q + r));
         int rc;
+        if ((rc = m->mw32_w[l].upload(wf.data(), wf.size() * 4))) return rc;
+        m->mpw32.w[l] = m->mw32_w[l].p;
         if ((rc = m->mw3_w[l].upload(w3.data(), w3.size() * 2))) return rc;
         m->mpw3.w[l] = m->mw3_w[l].p;
         if ((rc = m->mwbf_w[l].upload(wb.data(), wb.size() * 2))) return rc;
@@ -209,15 +221,17 @@ int pack_wide(b2h_model* m, const HostWeights& hw) {
         if ((rc = m->mw_bias[l].upload(bf.data(), bf.size() * 4))) return rc;
         m->mpw_bf.w[l] = m->mwbf_w[l].p;
         m->mpw_h.w[l] = m->mwh_w[l].p;
-        m->mpw_bf.bias[l] = m->mpw_h.bias[l] = m->mpw3.bias[l] = (const float*)m->mw_bias[l].p;
+        m->mpw_bf.bias[l] = m->mpw_h.bias[l] = m->mpw3.bias[l] = m->mpw32.bias[l] = (const float*)m->mw_bias[l].p;
     }
-    m->mpw_bf.pos_emb = m->mpw_h.pos_emb = m->mpw3.pos_emb = m->pos_emb;
+    m->mpw_bf.pos_emb = m->mpw_h.pos_emb = m->mpw3.pos_emb = m->mpw32.pos_emb = m->pos_emb;
     return B2H_OK;
 }
 
 // single-parameter aliases of the wide kernel for the launch macro
 template <bool FUSED> constexpr auto b2h_fwd_mfma16w_bf16 = b2h_fwd_mfma16w<PREC_BF16, FUSED>;
 template <bool FUSED> constexpr auto b2h_fwd_mfma16w_f16 = b2h_fwd_mfma16w<PREC_F16, FUSED>;
+template <bool FUSED> constexpr auto b2h_fwd_mfma_f32_narrow = b2h_fwd_mfma_f32<FUSED, false>;
+template <bool FUSED> constexpr auto b2h_fwd_mfma_f32_wide = b2h_fwd_mfma_f32<FUSED, true>;
 
 int pack_all(b2h_model* m, const HostWeights& hw) {
     m->w_absmax = 0.f;
@@ -312,16 +326,22 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
 }
 
 int resolve_kernel(const b2h_model* m, int kernel) {
-    if (kernel == B2H_KERNEL_AUTO) return m->C <= kMfmaWidth ? B2H_KERNEL_F32_MFMA : B2H_KERNEL_F32_VALU;
+    // AUTO = the faster of the two exact-fp32 kernels (profiles/r2_bf16/widths_8192x200.txt): the
+    // matrix-core kernel costs the same at every width of its geometry (<= 32: 2.66 G frames/s,
+    // 33..64: 0.77 G), the VALU kernel's cost grows with the width and is ahead only just above the
+    // geometry step (0.88 G at 33 channels, level at 40) and for the narrowest models (3.08 G at 8
+    // channels, 2.51 G at 10)
+    if (kernel == B2H_KERNEL_AUTO)
+        return (m->C <= 8 || (m->C > kMfmaWidth && m->C < 40)) ? B2H_KERNEL_F32_VALU : B2H_KERNEL_F32_MFMA;
     return kernel;
 }
 
 bool kernel_ok(const b2h_model* m, int k) {
     switch (k) {
         case B2H_KERNEL_F32_VALU: return m->C <= kMaxWidth;
-        case B2H_KERNEL_F32_MFMA: return m->C <= kMfmaWidth;
+        case B2H_KERNEL_F32_MFMA:
         case B2H_KERNEL_BF16_MFMA:
-        case B2H_KERNEL_F16_MFMA: return m->C <= kMaxWidth; // > 32 channels: the wide kernel
+        case B2H_KERNEL_F16_MFMA: return m->C <= kMaxWidth; // > 32 channels: the wide kernels
         case B2H_KERNEL_F16X3_MFMA: return m->C <= kMaxWidth && (!m->has_weights || m->w_absmax < kF16Max);
         default: return false;
     }
@@ -344,7 +364,8 @@ int set_conv_kernel_attributes() {
     if (dev >= 0 && dev < 64 && done[dev]) return B2H_OK;
     int rc;
     if ((rc = raise_lds_cap(b2h_fwd_f32_valu<true>)) || (rc = raise_lds_cap(b2h_fwd_f32_valu<false>)) ||
-        (rc = raise_lds_cap(b2h_fwd_mfma_f32<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f32<true>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma_f32<false, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f32<true, false>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma_f32<false, true>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f32<true, true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma_f16x3<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3<true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma_f16x3w<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3w<true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, true>)) ||
@@ -404,7 +425,7 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         // bit-identical frames.
         const bool wide = m->C > kMfmaWidth; // 33..64 channels: wave-per-chunk 16-bit kernel (kernel_mfma16w.h)
         int chunk_len = kChunk;
-        const bool wide3 = wide && k == B2H_KERNEL_F16X3_MFMA; // one 4-wave workgroup per CU
+        const bool wide3 = wide && (k == B2H_KERNEL_F16X3_MFMA || k == B2H_KERNEL_F32_MFMA); // one 4-wave workgroup per CU
         if (wide || (k != B2H_KERNEL_BF16_MFMA && k != B2H_KERNEL_F16_MFMA)) {
             const int64_t slots = (int64_t)m->num_cus * (wide3 ? 1 : 2) * kWavesPerBlock;
             for (int cand : {64, 32}) {
@@ -423,16 +444,19 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         if (fusedc) hipLaunchKernelGGL((KERN<true>), g, blk, LDS, st, x, y, (int)T, cps, chunk_len, nchunks, MP, fa);  \
         else hipLaunchKernelGGL((KERN<false>), g, blk, LDS, st, x, y, (int)T, cps, chunk_len, nchunks, MP, fa);        \
     } while (0)
-        if (wide3) {
+        if (wide3 && k == B2H_KERNEL_F16X3_MFMA) {
             const size_t lds = (size_t)kWavesPerBlock * 2 * kImg3W;
             B2H_LAUNCHC(b2h_fwd_mfma_f16x3w, lds, m->mpw3);
+        } else if (wide3) {
+            const size_t lds = (size_t)kWavesPerBlock * Geo32<true>::kImg;
+            B2H_LAUNCHC(b2h_fwd_mfma_f32_wide, lds, m->mpw32);
         } else if (wide) {
             const size_t lds = (size_t)kWavesPerBlock * kImgW;
             if (k == B2H_KERNEL_BF16_MFMA) B2H_LAUNCHC(b2h_fwd_mfma16w_bf16, lds, m->mpw_bf);
             else B2H_LAUNCHC(b2h_fwd_mfma16w_f16, lds, m->mpw_h);
         } else if (k == B2H_KERNEL_F32_MFMA) {
-            const size_t lds = (size_t)kWavesPerBlock * kRows * Prec<PREC_F32>::kRowBytes;
-            B2H_LAUNCHC(b2h_fwd_mfma_f32, lds, m->mp32);
+            const size_t lds = (size_t)kWavesPerBlock * Geo32<false>::kImg;
+            B2H_LAUNCHC(b2h_fwd_mfma_f32_narrow, lds, m->mp32);
         } else if (k == B2H_KERNEL_F16X3_MFMA) {
             const size_t lds = (size_t)kWavesPerBlock * 2 * kImg3; // hi + lo images = the fp32 image's bytes
             B2H_LAUNCHC(b2h_fwd_mfma_f16x3, lds, m->mp3);
@@ -892,7 +916,7 @@ const char* b2h_kernel_name(const b2h_model* m, int kernel) {
     if (!m) return "";
     switch (resolve_kernel(m, kernel)) {
         case B2H_KERNEL_F32_VALU: return "b2h_fwd_f32_valu";
-        case B2H_KERNEL_F32_MFMA: return "b2h_fwd_mfma_f32<false>";
+        case B2H_KERNEL_F32_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma_f32<false, true>" : "b2h_fwd_mfma_f32<false, false>";
         case B2H_KERNEL_BF16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<1, false>" : "b2h_fwd_mfma16<1, false>";
         case B2H_KERNEL_F16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<2, false>" : "b2h_fwd_mfma16<2, false>";
         case B2H_KERNEL_F16X3_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma_f16x3w<false>" : "b2h_fwd_mfma_f16x3<false>";

@@ -204,14 +204,30 @@ __device__ __forceinline__ StagedRows stage_rows(const ChunkCtx& cx, const float
 }
 
 // ---- exact-fp32 layers (v_mfma_f32_16x16x4_f32) -------------------------------
-template <int L, bool FUSED>
+// WIDE = false: conv_channels <= 32 (32-channel rows of 128 B, two k-groups of 16 per tap, two M-tiles,
+// slot map 8q + 4mt + r, 160 fragment registers, two waves per SIMD).
+// WIDE = true : conv_channels 33..64 (64-channel rows of 256 B, four k-groups per tap -- layer 1 has
+// 24|25 inputs = two --, four M-tiles, slot map 16q + 4mt + r; a hidden layer's fragments are 320
+// registers, so ONE wave per SIMD over the 512-entry register file, one 4-wave workgroup per CU).
+// No swizzle on these rows: one ds_read_b128 feeds 16 (32) MFMAs of 32 cycles, LDS is never the limit.
+template <bool WIDE> struct Geo32 {
+    static constexpr int kRowB = WIDE ? 256 : 128;
+    static constexpr int kChunks = kRowB / 16;
+    static constexpr int kImg = kRows * kRowB; // LDS bytes per wave: 18 / 36 KB
+    static __host__ __device__ constexpr int mt(int L) { return L == 3 ? 3 : (WIDE ? 4 : 2); }
+    static __host__ __device__ constexpr int groups(int L) { return (WIDE && L > 0) ? 4 : 2; }
+    static __device__ __forceinline__ int off(int P, int c) { return P * kRowB + (c << 4); }
+};
+
+template <int L, bool FUSED, bool WIDE>
 __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp) {
-    constexpr int MT = (L == 3) ? 3 : 2;
+    using G = Geo32<WIDE>;
+    constexpr int MT = G::mt(L), NG = G::groups(L), MTH = G::mt(0);
     constexpr int h = 6 - 2 * L;
     const int lo = max(cx.s - h, 0), hi = min(cx.e + h, cx.T);
     const int ntiles = (hi - lo + 15) >> 4;
 
-    f32x4 A[MT][kTaps][2]; // [.][tap][g][j]: in-channel 16g + 4q + j
+    f32x4 A[MT][kTaps][NG]; // [.][tap][g][j]: in-channel 16g + 4q + j
     f32x4 bias[MT];
     {
         const f32x4* wp = reinterpret_cast<const f32x4*>(mp.w[L]);
@@ -220,7 +236,7 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
 #pragma unroll
             for (int s = 0; s < kTaps; ++s)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) A[mt][s][g] = wp[((mt * kTaps + s) * 2 + g) * 64 + cx.lane];
+                for (int g = 0; g < NG; ++g) A[mt][s][g] = wp[((mt * kTaps + s) * NG + g) * 64 + cx.lane];
         const f32x4* bp = reinterpret_cast<const f32x4*>(mp.bias[L]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) bias[mt] = bp[mt * 4 + cx.q];
@@ -240,8 +256,8 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
         for (int s = 0; s < kTaps; ++s) {
             const int Pr = tau + cx.tcol + s - kPad + pin;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(cx.lds + lds_off<128>(Pr, 4 * g + cx.q));
+            for (int g = 0; g < NG; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(cx.lds + G::off(Pr, 4 * g + cx.q));
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -251,22 +267,22 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
         }
         const int t = tau + cx.tcol;
         if constexpr (L < 3) {
-            f32x4 o[2];
+            f32x4 o[MTH];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTH; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) // max(v, 0) as one v_max_i32 on the bits
                     o[mt][r] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, (float)acc[mt][r]), 0));
             if (tau + 16 > cx.T) { // only the tile that crosses the sequence end: frames >= T are padding
                 const bool inside = t < cx.T;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MTH; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[mt][r] = inside ? o[mt][r] : 0.f;
             }
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) // channels 8q + 4mt .. +3  ->  16-B chunk 2q + mt
-                *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(t + pout, 2 * cx.q + mt)) = o[mt];
+            for (int mt = 0; mt < MTH; ++mt) // channels (8|16)q + 4mt .. +3  ->  16-B chunk (2|4)q + mt
+                *reinterpret_cast<f32x4*>(cx.lds + G::off(t + pout, MTH * cx.q + mt)) = o[mt];
         } else {
             hs.store(cx, acc, 0);
             hs.off += 16 * kOutCh * 4;
@@ -274,44 +290,50 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
         }
     }
     if constexpr (L < 3) {
-        if (hi == cx.T) {
+        if (hi == cx.T) { // rows T, T+1 of the next layer's input: zero unless a tile covered them
             const int covered = lo + 16 * ntiles;
-            const int t = cx.T + (cx.lane >> 3);
-            if (cx.lane < 16 && t >= covered)
-                *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(t + pout, cx.lane & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int t = cx.T + cx.lane / G::kChunks;
+            if (cx.lane < 2 * G::kChunks && t >= covered)
+                *reinterpret_cast<f32x4*>(cx.lds + G::off(t + pout, cx.lane % G::kChunks)) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         wave_lds_sync();
     }
 }
 
 // ---- input staging: (T,24) fp32 rows -> LDS image of layer-1 input ------------
+template <bool WIDE>
 __device__ __forceinline__ void stage_input32(const ChunkCtx& cx, const float* __restrict__ xs, int pos_emb) {
+    using G = Geo32<WIDE>;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const StagedRows st = stage_rows(
         cx, xs, pos_emb,
-        [&](int P, int c4, float4 w) { *reinterpret_cast<float4*>(cx.lds + lds_off<128>(P, c4)) = w; },
-        [&](int P, float pe) { // channel padding 24..31 = chunks 6, 7
-            *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(P, 6)) = f32x4{pe, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(P, 7)) = z4;
+        [&](int P, int c4, float4 w) { *reinterpret_cast<float4*>(cx.lds + G::off(P, c4)) = w; },
+        [&](int P, float pe) { // channel padding 24..31 = chunks 6, 7 (layer 1 reads chunks 0..7 only)
+            *reinterpret_cast<f32x4*>(cx.lds + G::off(P, 6)) = f32x4{pe, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(cx.lds + G::off(P, 7)) = z4;
         });
-    // zero rows: t in [-8,0) at the sequence start (all layers' low padding) and t = T, T+1 at its end
-    if (cx.s == 0) *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(cx.lane >> 3, cx.lane & 7)) = z4;
-    if (st.at_end && cx.lane < 16)
-        *reinterpret_cast<f32x4*>(cx.lds + lds_off<128>(st.P0 + st.nrows + (cx.lane >> 3), cx.lane & 7)) = z4;
+    // zero rows (whole rows: later layers read them whole): t in [-8,0) at the sequence start (all
+    // layers' low padding) and t = T, T+1 at its end
+    if (cx.s == 0)
+        for (int i = cx.lane; i < 8 * G::kChunks; i += 64)
+            *reinterpret_cast<f32x4*>(cx.lds + G::off(i / G::kChunks, i % G::kChunks)) = z4;
+    if (st.at_end && cx.lane < 2 * G::kChunks)
+        *reinterpret_cast<f32x4*>(cx.lds + G::off(st.P0 + st.nrows + cx.lane / G::kChunks, cx.lane % G::kChunks)) = z4;
     wave_lds_sync();
 }
 
-// One wave per (sequence, chunk); no workgroup barrier anywhere.  Two 4-wave workgroups per CU by
-// LDS = 2 waves per SIMD, so a wave may use 256 VGPRs (keeps the accumulators out of AGPRs).
-template <bool FUSED>
-__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void b2h_fwd_mfma_f32(
+// One wave per (sequence, chunk); no workgroup barrier anywhere.  Narrow: two 4-wave workgroups per CU by
+// LDS = 2 waves per SIMD, each within 256 VGPRs (keeps the accumulators out of AGPRs).  Wide: one.
+template <bool FUSED, bool WIDE>
+__global__ __launch_bounds__(64 * kWavesPerBlock, WIDE ? 1 : 2) void b2h_fwd_mfma_f32(
     const float* __restrict__ x, float* __restrict__ y, int T, int chunks_per_seq, int chunk_len,
     int64_t nchunks, MfmaParams mp, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem_mfma[];
     ChunkCtx cx;
-    if (!chunk_ctx(cx, smem_mfma, kRows * Prec<PREC_F32>::kRowBytes, y, T, chunks_per_seq, chunk_len, nchunks, fa)) return;
-    stage_input32(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
-    layer32<0, FUSED>(cx, mp); layer32<1, FUSED>(cx, mp); layer32<2, FUSED>(cx, mp); layer32<3, FUSED>(cx, mp);
+    if (!chunk_ctx(cx, smem_mfma, Geo32<WIDE>::kImg, y, T, chunks_per_seq, chunk_len, nchunks, fa)) return;
+    stage_input32<WIDE>(cx, x + cx.seq * (int64_t)T * kInCh, mp.pos_emb);
+    layer32<0, FUSED, WIDE>(cx, mp); layer32<1, FUSED, WIDE>(cx, mp);
+    layer32<2, FUSED, WIDE>(cx, mp); layer32<3, FUSED, WIDE>(cx, mp);
 }
 
 } // namespace b2h

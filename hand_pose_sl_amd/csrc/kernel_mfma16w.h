@@ -50,13 +50,17 @@ __device__ __forceinline__ void layer16w(const ChunkCtx& cx, const MfmaParams& m
     vec8 A[MT][kTaps][KS]; // in-positions 32ks + 8q + j of out-channel slot (lane & 15)
     f32x4 bias[MT];
     {
-        const vec8* wp = reinterpret_cast<const vec8*>(mp.w[L]);
+        // buffer loads: one descriptor in SGPRs + the lane offset, fragment offsets as immediates /
+        // soffset -- 64-bit per-fragment addresses (40 KB span) cost 20 VGPRs and spilled
+        const __amdgpu_buffer_rsrc_t wrs = make_rsrc(mp.w[L], MT * kTaps * KS * 1024);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int s = 0; s < kTaps; ++s)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) A[mt][s][ks] = wp[((mt * kTaps + s) * KS + ks) * 64 + cx.lane];
+                for (int ks = 0; ks < KS; ++ks)
+                    A[mt][s][ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                wrs, cx.lane * 16, ((mt * kTaps + s) * KS + ks) * 1024, 0));
         const f32x4* bp = reinterpret_cast<const f32x4*>(mp.bias[L]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) bias[mt] = bp[mt * 4 + cx.q];

@@ -35,15 +35,17 @@ __device__ __forceinline__ void layer3w(const ChunkCtx& cx, const MfmaParams& mp
     f16x8 Ah[MT][kTaps][KS], Al[MT][kTaps][KS]; // in-positions 32ks + 8q + j of out-channel slot (lane & 15)
     f32x4 bias[MT];
     {
-        const f16x8* wp = reinterpret_cast<const f16x8*>(mp.w[L]); // [mt][tap][ks][hi|lo][lane]
+        // [mt][tap][ks][hi|lo][lane] x 16 B, buffer loads (descriptor + lane offset: see kernel_mfma16w.h)
+        const __amdgpu_buffer_rsrc_t wrs = make_rsrc(mp.w[L], MT * kTaps * KS * 2048);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int s = 0; s < kTaps; ++s)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    Ah[mt][s][ks] = wp[((((mt * kTaps + s) * KS + ks) * 2 + 0) * 64) + cx.lane];
-                    Al[mt][s][ks] = wp[((((mt * kTaps + s) * KS + ks) * 2 + 1) * 64) + cx.lane];
+                    const int f = ((mt * kTaps + s) * KS + ks) * 2048;
+                    Ah[mt][s][ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, cx.lane * 16, f, 0));
+                    Al[mt][s][ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, cx.lane * 16, f + 1024, 0));
                 }
         const f32x4* bp = reinterpret_cast<const f32x4*>(mp.bias[L]);
 #pragma unroll

@@ -543,6 +543,12 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
         } else if (st.type == ST_SET || (B2H_ABLATE & 256)) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) { cur[m] = acc[m]; resid[m] = acc[m]; }
+        } else if constexpr (H3) {
+            // ST_STORE: the operand that carries over is (bh, bl); defining `cur` on this path too makes
+            // it dead across the back edge, so its 32 registers are free during the GEMM (the kernel
+            // spilled 14 without this)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) cur[m] = acc[m];
         }
         if constexpr (H3) {
             if (st.type != ST_STORE) chain_split(cur, bh, bl); // ST_STORE leaves the operand as it is

@@ -41,9 +41,11 @@ typedef enum b2h_status {
 
 /* Which hand-written kernel computes the four-layer stack. */
 typedef enum b2h_kernel {
-    B2H_KERNEL_AUTO = 0,      /* F32_MFMA when it supports the width, else F32_VALU   */
-    B2H_KERNEL_F32_VALU = 1,  /* fp32 FMA on the vector ALU; any conv_channels <= 64   */
-    B2H_KERNEL_F32_MFMA = 2,  /* exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32); conv_channels <= 32 */
+    B2H_KERNEL_AUTO = 0,      /* the faster exact-fp32 kernel for the model's width: F32_MFMA, except
+                                 F32_VALU at conv_channels <= 8 and 33..39 (measured crossovers) */
+    B2H_KERNEL_F32_VALU = 1,  /* fp32 FMA on the vector ALU; any conv_channels <= 64 (cross-check kernel) */
+    B2H_KERNEL_F32_MFMA = 2,  /* exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32); any conv_channels <= 64
+                                 (33..64: a one-wave-per-SIMD wide variant) */
     B2H_KERNEL_BF16_MFMA = 3, /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16); any
                                  conv_channels <= 64 (33..64: the wide kernel, two k-steps per tap) */
     B2H_KERNEL_F16_MFMA = 4,  /* fp16 operands, fp32 accumulate (v_mfma_f32_16x16x32_f16); <= 64 likewise */

@@ -41,9 +41,9 @@ def _model(rec, prec, dev):
 
 
 def _supported(rec, prec):
-    """conv_channels 33..64: the wide matrix-core kernels (bf16 / f16: kernel_mfma16w.h, f16x3:
-    kernel_mfma3w.h) and the fp32 VALU kernel; the exact-fp32 MFMA kernel stops at 32."""
-    return rec["C"] <= 32 or prec != "f32_mfma"
+    """Every kernel runs every width 1..64 (33..64: the wide variants -- bf16 / f16 kernel_mfma16w.h,
+    f16x3 kernel_mfma3w.h, exact fp32 Geo32<true> in kernel_mfma.h)."""
+    return rec["C"] <= 64
 
 
 def _tol(rec, prec):
@@ -149,12 +149,12 @@ def test_config4_stream_sharded_equals_one_launch(prec, cuda_device):
     assert np.abs(y[idx].cpu().numpy() - ref).max() <= TOL[prec]
 
 
-@pytest.mark.parametrize("prec", ["bf16", "f16", "f16x3", "f32_valu"])
+@pytest.mark.parametrize("prec", ["bf16", "f16", "f16x3", "f32_mfma", "f32_valu"])
 @pytest.mark.parametrize("C", [33, 40, 47, 48, 49, 56, 63, 64])
 def test_wide_models_vs_oracle(C, prec, cuda_device):
     """conv_channels is a free integer in the reference (run.py:37, HandPoseModels.py:24-32).  Widths
-    33..64 run on the wide matrix-core kernels (two 32-channel k-steps per tap, four M-tiles; bf16 / f16,
-    and the fp32-grade f16 hi/lo split at one wave per SIMD);
+    33..64 run on the wide matrix-core kernels (64-channel rows, four M-tiles; bf16 / f16 at two waves
+    per SIMD, the fp32-grade f16 hi/lo split and exact fp32 at one wave per SIMD);
     checked against the oracle (reference bars) and the oracle's operand-rounding model on lengths
     around the tile and chunk edges, with pos_emb (T = 100), small and large batches (different
     chunkings must agree bit for bit), the fused transforms and batch independence."""
@@ -163,7 +163,10 @@ def test_wide_models_vs_oracle(C, prec, cuda_device):
         m = hps.ConvModel(C, "ReLU", pos_emb, precision=prec).to(cuda_device).eval()
         state = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
         assert m.kernel_name() == {"bf16": "b2h_fwd_mfma16w<1, false>", "f16": "b2h_fwd_mfma16w<2, false>",
-                                   "f16x3": "b2h_fwd_mfma_f16x3w<false>", "f32_valu": "b2h_fwd_f32_valu"}[prec]
+                                   "f16x3": "b2h_fwd_mfma_f16x3w<false>", "f32_mfma": "b2h_fwd_mfma_f32<false, true>",
+                                   "f32_valu": "b2h_fwd_f32_valu"}[prec]
+        # AUTO = the faster exact-fp32 kernel: VALU just above the 32-channel step, the matrix cores from 40
+        assert m.kernel_name("fp32") == ("b2h_fwd_f32_valu" if C < 40 else "b2h_fwd_mfma_f32<false, true>")
         g = torch.Generator().manual_seed(C)
         for T in lengths:
             x = torch.rand((4, T, 12, 2), generator=g) - 0.5

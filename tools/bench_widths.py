@@ -14,7 +14,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 x = torch.rand((B, T, 12, 2), device=dev, generator=g) - 0.5
 y = torch.empty((B, T, 21, 2), device=dev)
 out = {"B": B, "T": T, "rows": []}
-for C in (8, 16, 30, 32, 33, 40, 48, 56, 64):
+for C in (8, 10, 12, 16, 30, 32, 33, 36, 40, 48, 56, 64):
     torch.manual_seed(C)
     m = hps.ConvModel(C, "ReLU", False).to(dev).eval()
     for prec in ("bf16", "f16", "f16x3", "f32_mfma", "f32_valu"):
