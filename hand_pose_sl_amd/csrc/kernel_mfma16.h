@@ -17,7 +17,8 @@
 //                starts from the bias fragment; ReLU (integer max), zero-padding
 //                mask (last tile only) and the 16-bit cast stay in registers; one
 //                ds_write_b128 per lane puts the tile back, 2 rows lower (in-place
-//                image, see kernel_mfma.h); the head stores fp32 straight to y.
+//                image, see kernel_mfma.h); the head's fp32 tile (16 x 168 B) turns once through
+//                already-consumed rows of the image and leaves as three lane-linear stores.
 //   No workgroup barrier after the weight copy; waves never exchange data.
 //
 // HBM traffic per frame = 96 B read + 168 B written (the algorithmic minimum);
@@ -242,11 +243,26 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
 
     // head only: this chunk's output rows [s, e) as a buffer (so that byte offsets stay small
     // however long the sequence is), lane byte offset within tile 0
+    // The 16 x 168 B of a head tile go through LDS once more so that they leave as three lane-linear
+    // stores (1 KiB contiguous per instruction) instead of 16 row segments of 64 B per instruction:
+    // the same bytes, 7-8 % faster next to the input stream (tools/membench_seq.hip, "mixed seq linear"
+    // vs "head-pattern").  Staging area = bytes [0, 2688 + 16) of the wave's own image: when tile j's
+    // epilogue runs, the fragments of tiles <= j + 2 are in registers and tile j + 3 reads rows
+    // >= 16 (j + 3), i.e. bytes >= 3072 (lo + pin - 2 == 0 in the head).  LDS operations of one wave
+    // execute in order, so neither the read-back nor the next tile's staging needs a wait.
+    typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
     __amdgpu_buffer_rsrc_t yrs;
-    int yoff = 0;
+    int yoff = 0, yoff2 = 0;
+    lds_char *stw = nullptr, *stw2a = nullptr, *stw2b = nullptr, *strd = nullptr;
     if constexpr (L == 3) { // lo == s here
         yrs = make_rsrc(yseq + (int64_t)lo * kOutCh, (g.e - lo) * (kOutCh * 4));
-        yoff = tcol * (kOutCh * 4) + 16 * q;
+        yoff = lane * 16;
+        yoff2 = lane < (16 * kOutCh * 4 - 2048) / 16 ? lane * 16 : 0x40000000; // third store: 640 B = 40 lanes
+        stw = (lds_char*)lds + tcol * (kOutCh * 4) + 16 * q;
+        lds_char* dummy = (lds_char*)lds + 16 * kOutCh * 4;   // lanes without channels park their 8 B here
+        stw2a = q < 3 ? stw + 128 : dummy;                    // channels 32 + 4q, +1 (q = 2: 40, 41)
+        stw2b = q < 2 ? stw + 136 : dummy + 8;                // channels 34 + 4q, +1
+        strd = (lds_char*)lds + lane * 16;
     }
     // M: the 10 (15) MFMAs of one tile on fragments already in registers.
     auto mma = [&](f32x4 (&acc)[MT], const vec8 (&Bf)[kTaps]) {
@@ -278,42 +294,33 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
                              pack2<PREC>(v[6], v[7])};
             *(lds_u32x4*)(wr + k * 1024) = o;
         } else {
-            {
-                // lane (tcol,q) owns channels 16mt + 4q .. +3 of its frame: 16 B at
-                // row offset 168 (t - s) + 64 mt + 16 q; frames >= e fall outside the descriptor
-                const bool dead = FUSED && (tq + 16 * k >= nvalid); // tail mask (per lane)
+            // lane (tcol,q) owns channels 16mt + 4q .. +3 of its frame: 16 B at byte 168 (t - lo) + 64 mt
+            // + 16 q of the tile's rows (8-byte aligned: 8-byte LDS writes)
+            const bool dead = FUSED && (tq + 16 * k >= nvalid); // tail mask (per lane)
+            f32x4 v[3];
 #pragma unroll
-                for (int mt = 0; mt < 3; ++mt) {
-                    f32x4 v = acc[mt];
-                    if constexpr (FUSED) {
-                        v = v * mul;                               // x factor, or x 1.0f (exact)
-                        if (dead) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    const int so = sbase + k * (16 * kOutCh * 4) + mt * 64;
-                    if constexpr (FUSED) __builtin_amdgcn_sched_barrier(0); // store + its wait states stay adjacent (below)
-                    if (mt < 2 || q < 2)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff, so, 0);
-                    else if (q == 2) // channels 40, 41
-                        // (elements passed BY VALUE: __builtin_bit_cast on an ext-vector element
-                        // lvalue reads element 0 in this clang)
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])},
-                                                              yrs, yoff, so, 0);
-                    if constexpr (FUSED) {
-                        // Store-data write-after-read hazard on gfx950 (hipcc, ROCm 7.2 pads nothing here):
-                        // the fused epilogue computes the NEXT M-tile's vector (v_pk_mul_f32) into the
-                        // registers this store is still reading; issued back to back, the store picks up
-                        // the new value for its second dword in the last lanes of each 16-lane group
-                        // (out[mt][1] = acc[mt+1][3] x mul at tcol 12..15).  It only bit when an epilogue
-                        // ran without MFMAs in between: head layer with an odd tile count, last tile full
-                        // (T mod 32 in 13..16); found by tools/stress_conv.py, pinned by
-                        // test_fused_every_length.  Four wait states between a store and what follows it.
-                        // (fenced on both sides -- above the store and here: a memory clobber alone keeps
-                        // neither VALU instructions nor MFMAs from moving between the store and the nop)
-                        asm volatile("s_nop 3" ::: "memory");
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+            for (int mt = 0; mt < 3; ++mt) {
+                v[mt] = acc[mt];
+                if constexpr (FUSED) {
+                    v[mt] = v[mt] * mul;                               // x factor, or x 1.0f (exact)
+                    if (dead) v[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                *(lds_f32x2*)(stw + 64 * mt) = f32x2{v[mt][0], v[mt][1]};
+                *(lds_f32x2*)(stw + 64 * mt + 8) = f32x2{v[mt][2], v[mt][3]};
+            }
+            *(lds_f32x2*)stw2a = f32x2{v[2][0], v[2][1]};
+            *(lds_f32x2*)stw2b = f32x2{v[2][2], v[2][3]};
+            // back out, lane-linear; frames >= e are bytes past the descriptor (range check per dword)
+            const int so = sbase + k * (16 * kOutCh * 4);
+            u32x4 o[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) o[i] = *(lds_u32x4*)(strd + 1024 * i);
+            __builtin_amdgcn_raw_buffer_store_b128(o[0], yrs, yoff, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o[1], yrs, yoff, so + 1024, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o[2], yrs, yoff2, so + 2048, 0);
         }
     };
     // F: the five fragments of the tile k tiles ahead.  Unconditional: past the last tile it reads

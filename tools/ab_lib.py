@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
-"""GPU box: same-process A/B of two builds of libb2h.so on the bench shape, interleaved rounds
-(cdna_hip_programming.md rule 24).  Each library is loaded under its own ctypes handle.
-    python tools/ab_lib.py <libA.so> <libB.so> [precision=bf16] [seqs=65536] [T=200]"""
+"""GPU box: same-process A/B of two (or more) builds of libb2h.so on the bench shape, interleaved
+rounds (cdna_hip_programming.md rule 24).  Each library is loaded under its own ctypes handle.
+    python tools/ab_lib.py <libA.so> <libB.so> [...] [precision=bf16] [seqs=65536] [T=200]"""
 import ctypes, os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hand_pose_sl_amd import _lib
 
-paths = sys.argv[1:3]
-prec = sys.argv[3] if len(sys.argv) > 3 else "bf16"
-S = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
-T = int(sys.argv[5]) if len(sys.argv) > 5 else 200
+paths = [a for a in sys.argv[1:] if a.endswith(".so")]
+rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
+prec = rest[0] if len(rest) > 0 else "bf16"
+S = int(rest[1]) if len(rest) > 1 else 65536
+T = int(rest[2]) if len(rest) > 2 else 200
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 import torch.nn as nn
@@ -38,11 +39,11 @@ def t(lib, h, y, iters):
     return ms.value
 for lib, h, y in libs:
     t(lib, h, y, 20)
-res = [[], []]
+res = [[] for _ in libs]
 for r in range(12):
     for i, (lib, h, y) in enumerate(libs):
         res[i].append(t(lib, h, y, 40))
 torch.cuda.synchronize()
-print("outputs identical:", torch.equal(libs[0][2], libs[1][2]))
+print("outputs identical to the first:", [bool(torch.equal(libs[0][2], l[2])) for l in libs[1:]])
 for i, p in enumerate(paths):
     print(f"{p}: median {statistics.median(res[i])*1e3:.1f} us  min {min(res[i])*1e3:.1f} us  ({S*T/statistics.median(res[i])/1e6:.2f} G frames/s)")

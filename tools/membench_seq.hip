@@ -5,6 +5,7 @@
 // walks one contiguous window (the pattern of the runtime's fill kernel, __amd_rocclr_fillBufferAligned:
 // 256 workgroups x 256 threads, 16 B per lane, grid stride).
 //   hipcc -O3 --offload-arch=gfx950 -o tools/_build/membench_seq tools/membench_seq.hip
+//   tools/_build/membench_seq [sequences per launch = 65536] [quick: W = 8 only]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -72,7 +73,8 @@ __global__ void k_ideal(const float4* __restrict__ x, float4* __restrict__ y, si
 }
 
 int main(int argc, char** argv) {
-    const int nseq = 65536;
+    const int nseq = argc > 1 ? atoi(argv[1]) : 65536; // sequences per launch
+    const bool quick = argc > 2;                       // only the W = 8 rows
     char *x, *y; unsigned* sink;
     CK(hipMalloc(&x, (size_t)nseq * XB)); CK(hipMalloc(&y, (size_t)nseq * YB)); CK(hipMalloc(&sink, 64));
     CK(hipMemset(x, 1, (size_t)nseq * XB)); CK(hipMemset(y, 0, (size_t)nseq * YB));
@@ -88,6 +90,7 @@ int main(int argc, char** argv) {
     };
     const double rb = (double)nseq * XB, wb = (double)nseq * YB;
     for (int W : {1, 2, 4, 8, 16}) {
+        if (quick && W != 8) continue;
         const dim3 g(256), b(64 * W);
         run("read-only  seq", W, rb, [&] { hipLaunchKernelGGL((k_seq<1, 0, 0>), g, b, 0, 0, x, y, nseq, sink); });
         run("write-only seq linear", W, wb, [&] { hipLaunchKernelGGL((k_seq<2, 0, 0>), g, b, 0, 0, x, y, nseq, sink); });
@@ -96,7 +99,7 @@ int main(int argc, char** argv) {
         run("mixed seq head-pattern", W, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0>), g, b, 0, 0, x, y, nseq, sink); });
         run("mixed seq head-pattern, adjacent waves", W, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 1>), g, b, 0, 0, x, y, nseq, sink); });
     }
-    {   // cache policies on the kernel's own shape (8 waves per CU, head-pattern stores)
+    if (!quick) {   // cache policies on the kernel's own shape (8 waves per CU, head-pattern stores)
         const dim3 g(256), b(64 * 8);
         run("mixed head-pattern, stores sc0", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 1, 0>), g, b, 0, 0, x, y, nseq, sink); });
         run("mixed head-pattern, stores sc1", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 16, 0>), g, b, 0, 0, x, y, nseq, sink); });
