@@ -41,6 +41,7 @@ SYMBOLS = {
     "b2h_target_transform": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                             ctypes.c_float, _vp]),
     "b2h_masked_l1": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp]),
+    "b2h_weighted_l1": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp]),
     "b2h_tenc_create": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.POINTER(_vp)]),
     "b2h_tenc_destroy": (ctypes.c_int, [_vp]),
     "b2h_tenc_set_kernel": (ctypes.c_int, [_vp, ctypes.c_int]),

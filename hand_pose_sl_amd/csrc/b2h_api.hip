@@ -882,21 +882,38 @@ int b2h_target_transform(const float* body, const float* hand, float* hand_out, 
     return B2H_OK;
 }
 
-int b2h_masked_l1(const float* pred, const float* target, const int64_t* n_frames, int64_t B, int64_t T,
-                  float* per_seq, float* loss, void* stream) {
-    if (B < 1 || T < 1) return fail(B2H_ERR_SHAPE, "masked L1 needs B >= 1 and T >= 1");
+namespace {
+int l1_metric(const float* pred, const float* target, const float* scores, const int64_t* n_frames, int64_t B,
+              int64_t T, float* per_seq, float* loss, void* stream) {
+    if (B < 1 || T < 1) return fail(B2H_ERR_SHAPE, "the L1 metrics need B >= 1 and T >= 1");
     if (B > 0x7fffffff || T > (1 << 24)) return fail(B2H_ERR_SHAPE, "shape too large");
     int rc;
     if ((rc = check_device_ptr(pred, "pred")) || (rc = check_device_ptr(target, "target")) ||
         (rc = check_device_ptr(per_seq, "per_seq")) || (rc = check_device_ptr(loss, "loss")) ||
-        (n_frames && (rc = check_device_ptr(n_frames, "n_frames"))))
+        (scores && (rc = check_device_ptr(scores, "scores"))) || (n_frames && (rc = check_device_ptr(n_frames, "n_frames"))))
         return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(b2h_masked_l1_seq_kernel, dim3((unsigned)B), dim3(256), 0, st, pred, target, n_frames, per_seq,
-                       (int)T);
-    hipLaunchKernelGGL(b2h_mean_kernel, dim3(1), dim3(256), 0, st, per_seq, loss, B);
+    if (scores)
+        hipLaunchKernelGGL(b2h_masked_l1_seq_kernel<true>, dim3((unsigned)B), dim3(256), 0, st, pred, target, scores,
+                           n_frames, per_seq, (int)T);
+    else
+        hipLaunchKernelGGL(b2h_masked_l1_seq_kernel<false>, dim3((unsigned)B), dim3(256), 0, st, pred, target, scores,
+                           n_frames, per_seq, (int)T);
+    hipLaunchKernelGGL(b2h_mean_kernel, dim3(1), dim3(256), 0, st, per_seq, loss, B, scores ? 0 : 1);
     HIP_TRY(hipGetLastError());
     return B2H_OK;
+}
+} // namespace
+
+int b2h_masked_l1(const float* pred, const float* target, const int64_t* n_frames, int64_t B, int64_t T,
+                  float* per_seq, float* loss, void* stream) {
+    return l1_metric(pred, target, nullptr, n_frames, B, T, per_seq, loss, stream);
+}
+
+int b2h_weighted_l1(const float* pred, const float* target, const float* scores, const int64_t* n_frames, int64_t B,
+                    int64_t T, float* per_seq, float* loss, void* stream) {
+    if (!scores) return fail(B2H_ERR_INVALID, "scores is NULL");
+    return l1_metric(pred, target, scores, n_frames, B, T, per_seq, loss, stream);
 }
 
 int b2h_model_info(const b2h_model* m, int* conv_channels, int* pos_emb, int* has_weights) {

@@ -174,9 +174,14 @@ __global__ __launch_bounds__(256) void b2h_target_transform_kernel(const float* 
 
 // maskedPoseL1 (steps/utils.py:413-428): per sequence the mean of |pred - target| over its
 // first n_frames[i] frames x 21 joints x 2, then the mean over the batch.
+// WEIGHTED = poderatedPoseL1 (steps/utils.py:431-452): |pred * s - target * s| with one score per
+// (frame, joint), both products rounded to fp32 before the subtraction as torch does; the batch
+// reduction is then a SUM (b2h_mean_kernel's `divide` = 0).
 // Pass 1: one workgroup per sequence -> per_seq[i] (fixed summation order: reproducible).
+template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void b2h_masked_l1_seq_kernel(const float* __restrict__ pred,
                                                                 const float* __restrict__ target,
+                                                                const float* __restrict__ scores,
                                                                 const int64_t* __restrict__ n_frames,
                                                                 float* __restrict__ per_seq, int T) {
     __shared__ float part[4];
@@ -186,25 +191,32 @@ __global__ __launch_bounds__(256) void b2h_masked_l1_seq_kernel(const float* __r
     const int64_t cnt = n * kOutCh;                       // floats of this sequence that count
     const float2* p = reinterpret_cast<const float2*>(pred + b * (int64_t)T * kOutCh);
     const float2* t = reinterpret_cast<const float2*>(target + b * (int64_t)T * kOutCh);
+    const float* sc = WEIGHTED ? scores + b * (int64_t)T * (kOutCh / 2) : nullptr;
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < cnt / 2; i += 256) {
+    for (int64_t i = threadIdx.x; i < cnt / 2; i += 256) { // one (frame, joint) per step
         const float2 a = p[i], c = t[i];
-        acc += fabsf(a.x - c.x) + fabsf(a.y - c.y);
+        if constexpr (WEIGHTED) {
+            const float w = sc[i];
+            acc += fabsf(__fmul_rn(a.x, w) - __fmul_rn(c.x, w)) + fabsf(__fmul_rn(a.y, w) - __fmul_rn(c.y, w));
+        } else {
+            acc += fabsf(a.x - c.x) + fabsf(a.y - c.y);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) per_seq[b] = (part[0] + part[1] + part[2] + part[3]) / (float)cnt; // 0/0 = NaN like torch
 }
-// Pass 2: one workgroup, mean of per_seq over the batch.
-__global__ __launch_bounds__(256) void b2h_mean_kernel(const float* __restrict__ v, float* __restrict__ out, int64_t n) {
+// Pass 2: one workgroup, mean (divide != 0) or sum of per_seq over the batch.
+__global__ __launch_bounds__(256) void b2h_mean_kernel(const float* __restrict__ v, float* __restrict__ out, int64_t n,
+                                                       int divide) {
     __shared__ float part[4];
     float acc = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += 256) acc += v[i];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = (part[0] + part[1] + part[2] + part[3]) / (float)n;
+    if (threadIdx.x == 0) out[0] = (part[0] + part[1] + part[2] + part[3]) / (divide ? (float)n : 1.0f);
 }
 
 } // namespace b2h

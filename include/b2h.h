@@ -129,6 +129,14 @@ int b2h_target_transform(const float* body, const float* hand, float* hand_out, 
 int b2h_masked_l1(const float* pred, const float* target, const int64_t* n_frames, int64_t B,
                   int64_t T, float* per_seq, float* loss, void* stream);
 
+/* The evaluation loop's other loss, `--loss confL1` = poderatedPoseL1 (steps/utils.py:431-452;
+ * chosen at traintest.py:41-42,207-208):
+ *   loss = sum_i( mean(|pred[i, :n_i] * s[i, :n_i, :, None] - target[i, :n_i] * s[i, :n_i, :, None]|) )
+ * -- a SUM over the batch (the class does not divide by B).  scores: device fp32 (B, T, 21), the
+ * OpenPose confidence of each target joint; everything else as b2h_masked_l1. */
+int b2h_weighted_l1(const float* pred, const float* target, const float* scores, const int64_t* n_frames,
+                    int64_t B, int64_t T, float* per_seq, float* loss, void* stream);
+
 /* TransformerEnc -------------------------------------------
  * The reference's second text-free body->hand model, `TransformerEnc(ninp, nhead, nhid, nout,
  * nlayers, dropout)` (HandPoseModels.py:118-178), as its CLIs build it: ninp = 24, nhead = 4,

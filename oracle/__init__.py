@@ -9,7 +9,7 @@ the reported-only CPU baseline.  hand_pose_sl_amd never imports it.
 Pinned by tests/golden/*.npz (vectors produced by the reference's own classes,
 tests/golden/make_golden.py) through tests/test_oracle.py.
 """
-from .c_oracle import (build_oracle, forward, forward_from_state, masked_l1, postprocess,  # noqa: F401
+from .c_oracle import (build_oracle, forward, forward_from_state, masked_l1, weighted_l1, postprocess,  # noqa: F401
                        preprocess)
 from .torch_port import TorchPort, torch_forward  # noqa: F401
 from .transformer_oracle import transformer_forward  # noqa: F401

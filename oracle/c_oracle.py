@@ -37,6 +37,8 @@ def _load():
                                                ctypes.POINTER(ctypes.c_int64)]
         lib.b2h_oracle_masked_l1.restype = ctypes.c_int
         lib.b2h_oracle_masked_l1.argtypes = [_fp, _fp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, _fp, _fp]
+        lib.b2h_oracle_weighted_l1.restype = ctypes.c_int
+        lib.b2h_oracle_weighted_l1.argtypes = [_fp, _fp, _fp, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_int, _fp, _fp]
         _lib = lib
     return _lib
 
@@ -127,6 +129,26 @@ def postprocess(pred, factor=1280.0, n_frames=None):
     if rc != 0:
         raise RuntimeError(f"b2h_oracle_postprocess failed: {rc}")
     return out
+
+
+def weighted_l1(pred, target, scores, lengths=None):
+    """poderatedPoseL1 (steps/utils.py:431-452): SUM over the batch of the per-utterance means of
+    |pred * s - target * s|.  Returns (loss float32 scalar, per_seq (B,))."""
+    lib = _load()
+    pred, target, scores = _f32(pred), _f32(target), _f32(scores)
+    B, T = pred.shape[:2]
+    if scores.shape != (B, T, 21):
+        raise ValueError(f"scores must be (B, T, 21), got {scores.shape}")
+    nf = None
+    if lengths is not None:
+        nfa = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
+        nf = nfa.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    per = np.empty((B,), dtype=np.float32)
+    loss = np.empty((1,), dtype=np.float32)
+    rc = lib.b2h_oracle_weighted_l1(_p(pred), _p(target), _p(scores), nf, B, T, _p(per), _p(loss))
+    if rc != 0:
+        raise RuntimeError(f"b2h_oracle_weighted_l1 failed: {rc}")
+    return loss[0], per
 
 
 def masked_l1(pred, target, lengths=None):

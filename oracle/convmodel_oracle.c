@@ -237,3 +237,32 @@ int b2h_oracle_masked_l1(const float* pred, const float* target, const int64_t* 
     return 0;
 }
 
+/* poderatedPoseL1 (`--loss confL1`, steps/utils.py:431-452):
+ *   loss = sum_i mean(|pred[i,:n_i] * s[i,:n_i,:,None] - target[i,:n_i] * s[i,:n_i,:,None]|)
+ * -- a SUM over the batch, the class does not divide by B.  scores (B, T, 21) weight both coordinates
+ * of a joint; the two products are rounded to fp32 before the subtraction, as torch does.
+ * Accumulates in double.  per_seq (B) may be NULL.  n_frames[b] == 0 gives NaN like torch.
+ */
+int b2h_oracle_weighted_l1(const float* pred, const float* target, const float* scores, const int64_t* n_frames,
+                           int B, int T, float* per_seq, float* loss) {
+    if (B < 1 || T < 1 || !pred || !target || !scores || !loss) return -1;
+    double total = 0.0;
+    for (int b = 0; b < B; ++b) {
+        int64_t n = n_frames ? n_frames[b] : T;
+        if (n < 0) n = 0;
+        if (n > T) n = T;
+        double acc = 0.0;
+        const size_t base = (size_t)b * T * 2 * N_HAND, cnt = (size_t)n * 2 * N_HAND;
+        const size_t sbase = (size_t)b * T * N_HAND;
+        for (size_t i = 0; i < cnt; ++i) {
+            const float s = scores[sbase + i / 2];
+            const float ps = pred[base + i] * s, ts = target[base + i] * s;
+            acc += fabs((double)(float)(ps - ts));
+        }
+        const double mean = acc / (double)cnt; /* 0/0 -> NaN */
+        if (per_seq) per_seq[b] = (float)mean;
+        total += mean;
+    }
+    *loss = (float)total;
+    return 0;
+}

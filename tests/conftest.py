@@ -33,7 +33,7 @@ def load_golden(name):
     return rec
 
 
-CONV_CASES = [n for n in golden_names() if not n.startswith(("transforms", "openpose", "metric", "tenc", "wire_formats", "predict_variants"))]
+CONV_CASES = [n for n in golden_names() if not n.startswith(("transforms", "openpose", "metric", "tenc", "wire_formats", "predict_variants", "validate"))]
 
 
 @pytest.fixture(scope="session")

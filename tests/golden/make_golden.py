@@ -185,6 +185,56 @@ def metric_case(utils, name, B, T, lengths, seed):
     print(f"{name}: loss {float(loss):.6f}  pixels {float(pix):.4f}")
 
 
+def weighted_metric_case(utils, name, B, T, lengths, seed):
+    """poderatedPoseL1 (`--loss confL1`, steps/utils.py:431-452): per utterance the mean of
+    |pred * score - target * score| over its first n frames, SUMMED over the batch (the class
+    does not divide by the batch size)."""
+    gen = torch.Generator().manual_seed(seed)
+    pred = torch.rand((B, T, 21, 2), generator=gen) - 0.5
+    tgt = torch.rand((B, T, 21, 2), generator=gen) - 0.5
+    scores = torch.rand((B, T, 21), generator=gen)
+    loss = utils.poderatedPoseL1()(pred, tgt, lengths, scores)
+    per_seq = torch.stack([torch.nn.functional.l1_loss(pred[i, :n] * scores[i, :n].unsqueeze(2),
+                                                       tgt[i, :n] * scores[i, :n].unsqueeze(2))
+                           for i, n in enumerate(lengths)])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), pred=pred.numpy(), target=tgt.numpy(), scores=scores.numpy(),
+                        lengths=np.array(lengths, dtype=np.int64), loss=loss.numpy(), per_seq=per_seq.numpy(),
+                        meta=np.array([B, T, 0, 0, seed], dtype=np.int64))
+    print(f"{name}: confL1 loss {float(loss):.6f}")
+
+
+def validate_case(utils, tt, hpm, name, seed):
+    """The evaluation loop itself, `validate(model, val_loader, criterion, device, args)`
+    (steps/traintest.py:168-213), on a three-batch synthetic loader, for both text-free models and both
+    losses the loop supports (`--loss L1` / `confL1`).  Batches as the reference's collate produces them
+    after the item transforms: body_kp = input_kp (B,T,12,2), target_kp (B,T,21,2), n_frames, target_conf."""
+    import types as _types
+    gen = torch.Generator().manual_seed(seed)
+    shapes = ((4, 100, [100, 37, 1, 64]), (3, 100, [99, 100, 12]), (2, 100, [50, 77]))
+    batches = []
+    for B, T, nf in shapes:
+        body = torch.rand((B, T, 12, 2), generator=gen) - 0.5
+        batches.append({"body_kp": body, "input_kp": body.clone(), "target_kp": torch.rand((B, T, 21, 2), generator=gen) - 0.5,
+                        "n_frames": list(nf), "target_conf": torch.rand((B, T, 21), generator=gen)})
+    torch.manual_seed(seed)
+    conv = hpm.ConvModel(30, "ReLU", False).eval()
+    torch.manual_seed(41)
+    tenc = hpm.TransformerEnc(ninp=12 * 2, nhead=4, nhid=128, nout=21 * 2, nlayers=4, dropout=0.5).eval()  # = tenc_weights.npz
+    rec = {k.replace(".", "_"): v.numpy() for k, v in conv.state_dict().items()}
+    for i, b in enumerate(batches):
+        rec.update({f"b{i}_body_kp": b["body_kp"].numpy(), f"b{i}_target_kp": b["target_kp"].numpy(),
+                    f"b{i}_n_frames": np.array(b["n_frames"], dtype=np.int64), f"b{i}_target_conf": b["target_conf"].numpy()})
+    for mname, model in (("Conv", conv), ("TransformerEnc", tenc)):
+        for lname, crit in (("L1", utils.maskedPoseL1()), ("confL1", utils.poderatedPoseL1())):
+            args = _types.SimpleNamespace(model=mname, loss=lname)
+            loader = [{k: (v.clone() if torch.is_tensor(v) else list(v)) for k, v in b.items()} for b in batches]
+            val = tt.validate(model, loader, crit, torch.device("cpu"), args)
+            rec[f"loss_{mname}_{lname}"] = np.array(val, dtype=np.float64)
+            print(f"{name}: validate({mname}, {lname}) = {val:.6f}")
+    rec["meta"] = np.array([len(batches), 100, 30, 0, seed], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+
+
 def tenc_cases(hpm):
     """TransformerEnc (HandPoseModels.py:118-178) as the CLIs build it (infer_utterance.py:99-101).
     One seeded model (weights stored once in tenc_weights.npz), several inputs."""
@@ -358,13 +408,17 @@ def main():
     tenc_transform_case(utils, hpm, "tenc_transforms_b6_t40", 40, [40, 1, 17, 39, 25, 8], 13)
     # evaluation metric
     metric_case(utils, "metric_b5_t60", 5, 60, [60, 1, 33, 59, 17], 31)
+    weighted_metric_case(utils, "metric_conf_b5_t60", 5, 60, [60, 1, 33, 59, 17], 37)
     # OpenPose JSON wire format + utterance staging
     _stub_io_deps()
     tpd = _load(os.path.join(REF, "dataloaders", "text_pose_dataset.py"), "ref_text_pose_dataset")
     openpose_case(tpd, utils, hpm, "openpose_short_n7_m12", 7, 12, 21)
     openpose_case(tpd, utils, hpm, "openpose_long_n30_m20", 30, 20, 22)
     # merged JSON + HDF5 row
-    wire_formats_case(tpd, _load_traintest(utils), "wire_formats", 23)
+    tt = _load_traintest(utils)
+    wire_formats_case(tpd, tt, "wire_formats", 23)
+    # the evaluation loop around the models (traintest.py:168-213), both losses it supports
+    validate_case(utils, tt, hpm, "validate_loop", 43)
     # --predict right_index / right_3fingers item builders and writers
     predict_variants_case(utils, "predict_variants", 29)
 

@@ -315,6 +315,12 @@ def test_c_abi_argument_checks(cuda_device):
     assert b"pred" in lib.b2h_last_error()
     assert lib.b2h_masked_l1(vp(d.data_ptr()), None, None, 2, 5, vp(out2.data_ptr()), vp(out2.data_ptr() + 8), None) == _lib.ERR_INVALID
     assert b"NULL" in lib.b2h_last_error()
+    sc = torch.ones(2 * 5 * 21, dtype=torch.float32, device=cuda_device)
+    assert lib.b2h_weighted_l1(vp(d.data_ptr()), vp(d.data_ptr()), vp(sc.data_ptr()), None, 2, 5, vp(out2.data_ptr()), vp(out2.data_ptr() + 8), None) == _lib.OK
+    assert lib.b2h_weighted_l1(vp(d.data_ptr()), vp(d.data_ptr()), None, None, 2, 5, vp(out2.data_ptr()), vp(out2.data_ptr() + 8), None) == _lib.ERR_INVALID
+    assert b"scores" in lib.b2h_last_error()
+    assert lib.b2h_weighted_l1(vp(d.data_ptr()), vp(d.data_ptr()), vp(host.data_ptr()), None, 2, 5, vp(out2.data_ptr()), vp(out2.data_ptr() + 8), None) == _lib.ERR_INVALID
+    assert lib.b2h_weighted_l1(vp(d.data_ptr()), vp(d.data_ptr()), vp(sc.data_ptr()), None, 0, 5, vp(out2.data_ptr()), vp(out2.data_ptr() + 8), None) == _lib.ERR_SHAPE
     assert lib.b2h_target_transform(vp(b.data_ptr()), vp(d.data_ptr()), vp(d.data_ptr()), 2, 5, 3, 1280.0, None) == _lib.OK
     assert lib.b2h_target_transform(vp(b.data_ptr()), vp(host.data_ptr()), vp(d.data_ptr()), 2, 5, 3, 1280.0, None) == _lib.ERR_INVALID
     assert lib.b2h_target_transform(vp(b.data_ptr()), vp(d.data_ptr()), vp(d.data_ptr()), 2, 5, 8, 1280.0, None) == _lib.ERR_INVALID
