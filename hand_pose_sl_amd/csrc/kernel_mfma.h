@@ -155,52 +155,61 @@ __device__ __forceinline__ bool chunk_ctx(ChunkCtx& cx, char* smem, int lds_per_
     return true;
 }
 
-// Input staging: the chunk's rows [s - 8, e + 8) clipped to the sequence, (T,24) fp32, as coalesced
-// float4 loads (8 in flight per lane: serial load->use exposes the HBM latency once per float4), the
-// reference's item transforms applied when fused, each float4 handed to put(P, c4, w) with P = its
-// physical LDS row (P(t,0) = t - s + 8) and c4 its float4 column (channels 4c4 .. 4c4+3); then
-// pad(P, pe) once per row for in-positions 24..31 (pos_emb: position 24 = t/100,
+// Input staging: the chunk's rows [s - 8, e + 8) clipped to the sequence, (T,24) fp32, as 12 lane-linear
+// buffer loads per lane, ALL in flight before the first use (128 rows x 6 float4 = 12 x 64; rows past
+// the chunk's last one come back as zeros from the range check and are written as such: they are
+// either the zero padding behind the sequence end or rows no valid frame depends on), the reference's
+// item transforms applied when fused, each float4 (channels 4c4 .. 4c4+3 of physical row P, P(t,0) =
+// t - s + 8) handed to put_at(byte offset, w).  Three load iterations cover exactly 32 rows, so a lane
+// needs only three (row, column) pairs and three image offsets off_of(P, c4); iteration u = 3G + jj
+// writes at off[jj] + 32 G ROWB (every layout's swizzle term is unchanged by a step of 32 rows).
+// Then pad(P, pe) once per row for in-positions 24..31 (pos_emb: position 24 = t/100,
 // HandPoseModels.py:71-75; the layer-1 weights are packed with the position channel moved to slot 24).
 // Returns (first physical row, number of rows, whether the chunk ends at the sequence end).
+constexpr int kStageRegs = 12;
+static_assert((kChunk + 2 * kHalo) * (kInCh / 4) == kStageRegs * 64, "12 float4 per lane cover the largest chunk");
 struct StagedRows { int P0, nrows; bool at_end; };
-template <typename PutF4, typename PutPad>
+template <int ROWB, typename OffOf, typename PutAt, typename PutPad>
 __device__ __forceinline__ StagedRows stage_rows(const ChunkCtx& cx, const float* __restrict__ xs, int pos_emb,
-                                                 PutF4 put, PutPad pad) {
+                                                 OffOf off_of, PutAt put_at, PutPad pad) {
     const int in_lo = max(cx.s - kHalo, 0), in_hi = min(cx.e + kHalo, cx.T);
     const int pin = 8 - cx.s;
     const int nf4 = (in_hi - in_lo) * (kInCh / 4);
-    const float4* src = reinterpret_cast<const float4*>(xs + (int64_t)in_lo * kInCh);
-    for (int i0 = cx.lane; i0 < nf4; i0 += 64 * 8) {
-        float4 v[8];
+    const int P0 = in_lo + pin; // 0, or 8 at the sequence start
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(xs + (int64_t)in_lo * kInCh, (B2H_ABLATE & 128) ? 0 : nf4 * 16);
+    float4 v[kStageRegs];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 64 * u;
-            v[u] = (i < nf4 && !(B2H_ABLATE & 128)) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int u = 0; u < kStageRegs; ++u)
+        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, cx.lane * 16, u * 1024, 0));
+    int rr[3], off[3];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 64 * u;
-            if (i >= nf4) continue;
-            const int rr = i / 6, c4 = i - rr * 6;
-            const int t = in_lo + rr;
-            float4 w = v[u];
-            if (cx.fa.flags & kPreChest) { // body -= body[:,1]  (steps/utils.py:203-210)
-                const float2 ch = *reinterpret_cast<const float2*>(xs + (int64_t)t * kInCh + 2);
-                w.x -= ch.x; w.y -= ch.y; w.z -= ch.x; w.w -= ch.y;
-            }
-            if (cx.fa.flags & kPreNorm) { // body / factor     (steps/utils.py:180-190)
-                w.x = w.x / cx.fa.factor; w.y = w.y / cx.fa.factor;
-                w.z = w.z / cx.fa.factor; w.w = w.w / cx.fa.factor;
-            }
-            put(t + pin, c4, w);
+    for (int jj = 0; jj < 3; ++jj) {
+        const int i = cx.lane + 64 * jj;
+        rr[jj] = i / 6;
+        off[jj] = off_of(P0 + rr[jj], i - rr[jj] * 6);
+    }
+    const int flags = __builtin_amdgcn_readfirstlane(cx.fa.flags);
+#pragma unroll
+    for (int u = 0; u < kStageRegs; ++u) {
+        const int G = u / 3, jj = u % 3;
+        float4 w = v[u];
+        if (flags & kPreChest) { // body -= body[:,1]  (steps/utils.py:203-210); joint 1 = channels 2, 3 of the row
+            const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(rs, (32 * G + rr[jj]) * (kInCh * 4) + 8, 0, 0);
+            const float cx_ = __uint_as_float(c[0]), cy_ = __uint_as_float(c[1]);
+            w.x -= cx_; w.y -= cy_; w.z -= cx_; w.w -= cy_;
         }
+        if (flags & kPreNorm) { // body / factor     (steps/utils.py:180-190)
+            w.x = w.x / cx.fa.factor; w.y = w.y / cx.fa.factor;
+            w.z = w.z / cx.fa.factor; w.w = w.w / cx.fa.factor;
+        }
+        put_at(off[jj] + G * 32 * ROWB, w);
     }
     const int nrows = in_hi - in_lo;
     for (int r = cx.lane; r < nrows; r += 64) {
         const int t = in_lo + r;
         pad(t + pin, pos_emb ? (float)t / 100.0f : 0.f);
     }
-    return StagedRows{in_lo + pin, nrows, in_hi == cx.T};
+    return StagedRows{P0, nrows, in_hi == cx.T};
 }
 
 // ---- exact-fp32 layers (v_mfma_f32_16x16x4_f32) -------------------------------
@@ -305,9 +314,9 @@ template <bool WIDE>
 __device__ __forceinline__ void stage_input32(const ChunkCtx& cx, const float* __restrict__ xs, int pos_emb) {
     using G = Geo32<WIDE>;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const StagedRows st = stage_rows(
-        cx, xs, pos_emb,
-        [&](int P, int c4, float4 w) { *reinterpret_cast<float4*>(cx.lds + G::off(P, c4)) = w; },
+    const StagedRows st = stage_rows<G::kRowB>(
+        cx, xs, pos_emb, [&](int P, int c4) { return G::off(P, c4); },
+        [&](int off, float4 w) { *reinterpret_cast<float4*>(cx.lds + off) = w; },
         [&](int P, float pe) { // channel padding 24..31 = chunks 6, 7 (layer 1 reads chunks 0..7 only)
             *reinterpret_cast<f32x4*>(cx.lds + G::off(P, 6)) = f32x4{pe, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(cx.lds + G::off(P, 7)) = z4;

@@ -129,11 +129,11 @@ __device__ __forceinline__ void layer16w(const ChunkCtx& cx, const MfmaParams& m
 template <int PREC>
 __device__ __forceinline__ void stage_input16w(const ChunkCtx& cx, const float* __restrict__ xs, int pos_emb) {
     const uint4 z4 = {0u, 0u, 0u, 0u};
-    const StagedRows st = stage_rows(
-        cx, xs, pos_emb,
-        [&](int P, int c4, float4 w) { // channels 4c4 .. 4c4+3: half (c4 & 1) of 16-B chunk c4 >> 1
-            *reinterpret_cast<uint2*>(cx.lds + lds_offw(P, c4 >> 1) + (c4 & 1) * 8) =
-                uint2{pack2<PREC>(w.x, w.y), pack2<PREC>(w.z, w.w)};
+    const StagedRows st = stage_rows<kWideRowB>(
+        cx, xs, pos_emb, // channels 4c4 .. 4c4+3: half (c4 & 1) of 16-B chunk c4 >> 1
+        [&](int P, int c4) { return lds_offw(P, c4 >> 1) + (c4 & 1) * 8; },
+        [&](int off, float4 w) {
+            *reinterpret_cast<uint2*>(cx.lds + off) = uint2{pack2<PREC>(w.x, w.y), pack2<PREC>(w.z, w.w)};
         },
         [&](int P, float pe) { // in-positions 24..31 = chunk 3; layer 1 reads chunks 0..3 only
             uint4 z = z4;

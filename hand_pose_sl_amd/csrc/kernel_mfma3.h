@@ -202,12 +202,12 @@ __device__ __forceinline__ void stage_input3(const ChunkCtx& cx, const float* __
     char* img_h = cx.lds;
     char* img_l = cx.lds + kImg3;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const StagedRows st = stage_rows(
-        cx, xs, pos_emb,
-        [&](int P, int c4, float4 w) { // channels 4c4 .. 4c4+3: half (c4 & 1) of 16-B chunk c4 >> 1
+    const StagedRows st = stage_rows<64>(
+        cx, xs, pos_emb, // channels 4c4 .. 4c4+3: half (c4 & 1) of 16-B chunk c4 >> 1
+        [&](int P, int c4) { return lds_off<64>(P, c4 >> 1) + (c4 & 1) * 8; },
+        [&](int off, float4 w) {
             f16x4 wh, wl;
             split4(w, wh, wl);
-            const int off = lds_off<64>(P, c4 >> 1) + (c4 & 1) * 8;
             *reinterpret_cast<f16x4*>(img_h + off) = wh;
             *reinterpret_cast<f16x4*>(img_l + off) = wl;
         },
