@@ -239,13 +239,15 @@ __device__ __forceinline__ void layer32(const ChunkCtx& cx, const MfmaParams& mp
     f32x4 A[MT][kTaps][NG]; // [.][tap][g][j]: in-channel 16g + 4q + j
     f32x4 bias[MT];
     {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(mp.w[L]);
+        const __amdgpu_buffer_rsrc_t wrs = make_rsrc(mp.w[L], MT * kTaps * NG * 1024); // [mt][tap][g][lane] x 16 B
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int s = 0; s < kTaps; ++s)
 #pragma unroll
-                for (int g = 0; g < NG; ++g) A[mt][s][g] = wp[((mt * kTaps + s) * NG + g) * 64 + cx.lane];
+                for (int g = 0; g < NG; ++g)
+                    A[mt][s][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                wrs, cx.lane * 16, ((mt * kTaps + s) * NG + g) * 1024, 0));
         const f32x4* bp = reinterpret_cast<const f32x4*>(mp.bias[L]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) bias[mt] = bp[mt * 4 + cx.q];
