@@ -65,16 +65,26 @@ class TransformerEnc(nn.Module):
         self._workspace = None
 
     def _tensors(self):
-        t = [self.pos_encoder.pe, self.pose2hidden_projection.weight, self.pose2hidden_projection.bias]
-        for layer in self.transformer_encoder.layers:
-            t += [layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias,
-                  layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias,
-                  layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
-                  layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias]
-        return t + [self.hidden2pose_projection.weight, self.hidden2pose_projection.bias]
+        # through the module dictionaries (53 tensors; nn.Module.__getattr__ would cost ~50 us per forward)
+        M = self._modules
+        p2h = M["pose2hidden_projection"]._parameters
+        t = [M["pos_encoder"]._buffers["pe"], p2h["weight"], p2h["bias"]]
+        for layer in M["transformer_encoder"]._modules["layers"]._modules.values():
+            lm = layer._modules
+            sa = lm["self_attn"]
+            for owner, names in ((sa._parameters, ("in_proj_weight", "in_proj_bias")),
+                                 (sa._modules["out_proj"]._parameters, ("weight", "bias")),
+                                 (lm["linear1"]._parameters, ("weight", "bias")), (lm["linear2"]._parameters, ("weight", "bias")),
+                                 (lm["norm1"]._parameters, ("weight", "bias")), (lm["norm2"]._parameters, ("weight", "bias"))):
+                t.append(owner[names[0]])
+                t.append(owner[names[1]])
+        h2p = M["hidden2pose_projection"]._parameters
+        t.append(h2p["weight"])
+        t.append(h2p["bias"])
+        return t
 
     def _ensure_handle(self):
-        dev = self.pose2hidden_projection.weight.device
+        dev = self._modules["pose2hidden_projection"]._parameters["weight"].device
         if dev.type != "cuda":
             raise RuntimeError("hand_pose_sl_amd.TransformerEnc runs on an MI355X only: call model.to('cuda') "
                                "first (there is no CPU path in the product)")
@@ -112,10 +122,10 @@ class TransformerEnc(nn.Module):
         lib = self._ensure_handle()
         if src.dim() != 4 or src.shape[2] * src.shape[3] != self.ninp:
             raise RuntimeError(f"expected input of shape (B, T, {self.ninp // 2}, 2), got {tuple(src.shape)}")
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise RuntimeError("hand_pose_sl_amd.TransformerEnc is inference-only: call model.eval() and wrap "
                                "the call in torch.no_grad()")
-        dev = self.pose2hidden_projection.weight.device
+        dev = self._modules["pose2hidden_projection"]._parameters["weight"].device
         x = src.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
         B, T = x.shape[0], x.shape[1]
         nf = None
