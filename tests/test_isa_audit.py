@@ -1,7 +1,11 @@
-"""Static check of the compiled gfx950 kernels (no GPU needed): no buffer/global store may have
-its data registers rewritten within two wait states (tools/store_war_audit.py) -- the
-store-data write-after-read hazard that produced wrong frames in the fused 16-bit kernel
-(DESIGN.md section 4).  Compiles b2h_api.hip once with --save-temps (about a minute)."""
+"""Static checks of the compiled gfx950 kernels (no GPU needed), from ONE compile of b2h_api.hip with
+--save-temps and hipcc's resource-usage remarks (about a minute):
+* no buffer/global store may have its data registers rewritten within two wait states
+  (tools/store_war_audit.py) -- the store-data write-after-read hazard that produced wrong frames in
+  the fused 16-bit kernel;
+* no kernel may spill or use scratch, and each must reach the occupancy its launch bound promises -- a
+  refactor once left the wide 16-bit kernel with 24 spilled VGPRs and serialised weight loads (-22 %),
+  visible only in a width sweep on the GPU."""
 import os
 import shutil
 import subprocess
@@ -12,20 +16,52 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_no_close_store_data_overwrite(tmp_path):
+@pytest.fixture(scope="module")
+def compiled(tmp_path_factory):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
+    tmp = tmp_path_factory.mktemp("isa")
     src = os.path.join(ROOT, "hand_pose_sl_amd", "csrc", "b2h_api.hip")
     r = subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function",
-                        "--save-temps", "-o", "x.so", src], cwd=tmp_path, capture_output=True, text=True, timeout=900)
+                        "--save-temps", "-Rpass-analysis=kernel-resource-usage", "-o", "x.so", src],
+                       cwd=tmp, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    listing = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
-    assert listing, os.listdir(tmp_path)
-    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "store_war_audit.py"),
-                        os.path.join(tmp_path, listing[0]), "2"], capture_output=True, text=True, timeout=300)
+    listing = [f for f in os.listdir(tmp) if f.endswith("gfx950.s")]
+    assert listing, os.listdir(tmp)
+    return os.path.join(tmp, listing[0]), r.stderr
+
+
+def test_no_close_store_data_overwrite(compiled):
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "store_war_audit.py"), compiled[0], "2"],
+                       capture_output=True, text=True, timeout=300)
     assert a.returncode == 0, a.stderr
     assert a.stdout.strip().splitlines()[-1] == "total 0", a.stdout
+
+
+def test_no_kernel_spills_and_promised_occupancy(compiled):
+    import re
+    kernels, cur = {}, None
+    for line in compiled[1].splitlines():
+        m = re.search(r"remark: [^ ]*\s+(.*?) \[-Rpass-analysis", line)
+        if not m:
+            continue
+        t = m.group(1).strip()
+        if t.startswith("Function Name:"):
+            cur = kernels.setdefault(t.split(":", 1)[1].strip(), {})
+        elif cur is not None and ":" in t:
+            k, v = t.rsplit(":", 1)
+            cur[k.strip()] = v.strip()
+    conv = {n: r for n, r in kernels.items() if "b2h_fwd" in n or "b2h_tenc_chain" in n or "b2h_attn" in n}
+    assert len(conv) >= 25, sorted(kernels)             # every instantiation of every kernel family was seen
+    for name, r in conv.items():
+        assert r["ScratchSize [bytes/lane]"] == "0" and r["VGPRs Spill"] == "0" and r["SGPRs Spill"] == "0", (name, r)
+    # launch bounds -> waves per SIMD the design counts on
+    want = {"b2h_fwd_mfma16I": 2, "b2h_fwd_mfma16wI": 2, "b2h_fwd_mfma_f16x3I": 2, "b2h_fwd_mfma_f16x3wI": 1, "b2h_tenc_chainI": 2}
+    for name, r in conv.items():
+        for key, occ in want.items():
+            if key in name:
+                assert int(r["Occupancy [waves/SIMD]"]) >= occ, (name, r)
 
 
 def test_audit_detects_the_pattern(tmp_path):
