@@ -65,6 +65,9 @@ def parse(argv=None):
     ap.add_argument("--seqs", type=int, default=262144, help="sequences per GPU per step")
     ap.add_argument("--frames", type=int, default=200, help="T, frames per sequence (--max-frames default, run.py:28)")
     ap.add_argument("--precision", default="bf16", choices=sorted(MFMA_PEAK_TFLOPS))
+    ap.add_argument("--precondition", type=int, default=200,
+                    help="untimed launches BEFORE the W warmup steps that bring the clock / power controller to its "
+                         "sustained state (the metric is a stream rate; reported as config.preconditioning_steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -306,6 +309,13 @@ def main():
     def step():
         _lib.check(lib.b2h_forward(model._handle, xp, yp, S, T, kern, st))
 
+    # Preconditioning (untimed, disclosed in the line): for the first ~30 ms after an idle gap the chip's
+    # clock / power controller has not settled and a launch takes 5-15 % longer (tools/sustain_probe.py,
+    # profiles/r2_bf16/ab_linear_stores.txt: 3.43 ms averaged over 5 launches, 3.05 over 20, 2.92 over 320).
+    # The metric is the rate of a sustained stream, so the stream runs for ~0.6 s before the W warmup
+    # steps; the timed region is still exactly K steps between barriers.
+    for _ in range(max(0, args.precondition)):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -326,6 +336,7 @@ def main():
                                f"path, {S} seq x {T} frames per GPU per step, inputs resident in HBM, "
                                f"sequence-sharded, no data-path collective in `value`",
                    "seqs_per_gpu": S, "frames_per_seq": T, "kernel": model.kernel_name(),
+                   "preconditioning_steps": max(0, args.precondition),
                    "parallelism": f"seq-shard x{world}", "gpus": gpus},
     }
     if backend is not None:

@@ -38,6 +38,7 @@ def test_one_json_line_with_the_contract_keys(cuda_device):
     assert d["unit"] == "frames/s" and d["data"] == "synthetic" and d["dtype"] == "bf16"
     assert d["value"] > 1e8 and abs(d["value"] - 2048 * 200 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["preconditioning_steps"] == 200     # untimed, disclosed; --precondition 0 turns it off
     assert len(d["config"]["gpus"]) == 1 and d["config"]["gpus"][0]["pci"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
