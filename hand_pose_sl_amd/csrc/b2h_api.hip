@@ -261,7 +261,8 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
         m->vp.wbuf_floats = wb;
         m->vp.pos_emb = m->pos_emb;
     }
-    if (m->C > kMfmaWidth) return pack_wide(m, hw); // 33..64 channels: the wide 16-bit kernel only
+    if (m->C > kMfmaWideWidth) return B2H_OK;       // 65..128 channels: the VALU kernel only
+    if (m->C > kMfmaWidth) return pack_wide(m, hw); // 33..64 channels: the wide matrix-core kernels
 
     // ---- MFMA layouts
     std::vector<unsigned char> ab(kPacked16, 0), ah(kPacked16, 0); // LDS images of the persistent kernel
@@ -332,7 +333,8 @@ int resolve_kernel(const b2h_model* m, int kernel) {
     // geometry step (0.88 G at 33 channels, level at 40) and for the narrowest models (3.08 G at 8
     // channels, 2.51 G at 10)
     if (kernel == B2H_KERNEL_AUTO)
-        return (m->C <= 8 || (m->C > kMfmaWidth && m->C < 40)) ? B2H_KERNEL_F32_VALU : B2H_KERNEL_F32_MFMA;
+        return (m->C <= 8 || (m->C > kMfmaWidth && m->C < 40) || m->C > kMfmaWideWidth) ? B2H_KERNEL_F32_VALU
+                                                                                          : B2H_KERNEL_F32_MFMA;
     return kernel;
 }
 
@@ -341,8 +343,8 @@ bool kernel_ok(const b2h_model* m, int k) {
         case B2H_KERNEL_F32_VALU: return m->C <= kMaxWidth;
         case B2H_KERNEL_F32_MFMA:
         case B2H_KERNEL_BF16_MFMA:
-        case B2H_KERNEL_F16_MFMA: return m->C <= kMaxWidth; // > 32 channels: the wide kernels
-        case B2H_KERNEL_F16X3_MFMA: return m->C <= kMaxWidth && (!m->has_weights || m->w_absmax < kF16Max);
+        case B2H_KERNEL_F16_MFMA: return m->C <= kMfmaWideWidth; // > 32 channels: the wide kernels
+        case B2H_KERNEL_F16X3_MFMA: return m->C <= kMfmaWideWidth && (!m->has_weights || m->w_absmax < kF16Max);
         default: return false;
     }
 }
@@ -364,6 +366,7 @@ int set_conv_kernel_attributes() {
     if (dev >= 0 && dev < 64 && done[dev]) return B2H_OK;
     int rc;
     if ((rc = raise_lds_cap(b2h_fwd_f32_valu<true>)) || (rc = raise_lds_cap(b2h_fwd_f32_valu<false>)) ||
+        (rc = raise_lds_cap(b2h_fwd_f32_valu<true, 3>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma_f32<false, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f32<true, false>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma_f32<false, true>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f32<true, true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma_f16x3<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3<true>)) ||
@@ -402,10 +405,11 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         return fail(B2H_ERR_INVALID, "B2H_POST_MASK_TAIL needs n_frames");
     const int k = resolve_kernel(m, kernel);
     if (!kernel_ok(m, k)) {
-        if (k == B2H_KERNEL_F16X3_MFMA)
+        if (k == B2H_KERNEL_F16X3_MFMA && m->C <= kMfmaWideWidth)
             return fail(B2H_ERR_UNSUPPORTED, "F16X3 kernel: a weight or bias is outside the f16 range (|w| >= 65504 or "
                                              "not finite); use the exact fp32 kernel");
-        return fail(B2H_ERR_UNSUPPORTED, "kernel variant does not support conv_channels=" + std::to_string(m->C));
+        return fail(B2H_ERR_UNSUPPORTED, "kernel variant does not support conv_channels=" + std::to_string(m->C) +
+                                             " (matrix-core kernels: <= 64; exact fp32 VALU kernel: <= 128)");
     }
 
     if (k == B2H_KERNEL_F32_VALU) {
@@ -413,7 +417,9 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
         const int64_t grid = B * tiles;
         if (grid > 0x7fffffff) return fail(B2H_ERR_SHAPE, "B*T too large for one launch");
         const size_t lds = ((size_t)2 * kValuRows * m->vp.act_stride + m->vp.wbuf_floats) * 4;
-        if (m->C > 56) {
+        if (m->C > 104) { // three work items per thread (kernel_valu.h)
+            hipLaunchKernelGGL((b2h_fwd_f32_valu<true, 3>), dim3((unsigned)grid), dim3(256), lds, st, x, y, (int)T, tiles, m->vp, fa);
+        } else if (m->C > 56) {
             hipLaunchKernelGGL(b2h_fwd_f32_valu<true>, dim3((unsigned)grid), dim3(256), lds, st, x, y, (int)T, tiles, m->vp, fa);
         } else {
             hipLaunchKernelGGL(b2h_fwd_f32_valu<false>, dim3((unsigned)grid), dim3(256), lds, st, x, y, (int)T, tiles, m->vp, fa);
@@ -797,7 +803,7 @@ int b2h_create(int conv_channels, const char* activation, int pos_emb, b2h_model
     if (!activation || std::strcmp(activation, "ReLU") != 0)
         return fail(B2H_ERR_INVALID, "activation must be \"ReLU\" (HandPoseModels.py:34-37)");
     if (conv_channels < 1 || conv_channels > kMaxWidth)
-        return fail(B2H_ERR_INVALID, "conv_channels must be in [1, 64]");
+        return fail(B2H_ERR_INVALID, "conv_channels must be in [1, 128]");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
         return fail(B2H_ERR_NO_DEVICE, "no HIP device visible (libb2h has no CPU path)");

@@ -14,8 +14,9 @@ constexpr int kPad = 2;        // padding
 constexpr int kInCh = 24;      // 12 joints x (x,y) (HandPoseModels.py:28)
 constexpr int kOutCh = 42;     // 21 joints x (x,y) (HandPoseModels.py:32)
 constexpr int kHalo = 8;       // receptive field 17 frames = +-8
-constexpr int kMaxWidth = 64;  // conv_channels supported by the VALU kernel
-constexpr int kMfmaWidth = 32; // conv_channels supported by the MFMA kernels
+constexpr int kMaxWidth = 128;     // conv_channels supported at all (exact fp32 VALU kernel; its LDS tile fills at 128)
+constexpr int kMfmaWideWidth = 64; // conv_channels supported by the matrix-core kernels (33..64: the wide variants)
+constexpr int kMfmaWidth = 32;     // conv_channels of the narrow matrix-core geometry
 
 // Pre/post-processing fused around the stack (values match include/b2h.h).
 constexpr int kPreChest = 1, kPreNorm = 2, kPostDenorm = 4, kPostMask = 8;

@@ -1,5 +1,5 @@
-// fp32 vector-ALU kernel: the generic-width path (any conv_channels <= 64) and
-// the device-side cross-check for the MFMA kernels.
+// fp32 vector-ALU kernel: the generic-width path (any conv_channels <= 128; the only kernel
+// above 64) and the device-side cross-check for the MFMA kernels.
 //
 // One 256-thread workgroup computes 64 output frames of one sequence through
 // all four layers (HandPoseModels.py:55-58).  It loads the 80 input frames it
@@ -16,7 +16,10 @@ namespace b2h {
 constexpr int kValuTile = 64;
 constexpr int kValuRows = kValuTile + 2 * kHalo; // 80
 
-template <bool WIDE> // WIDE: in-channel loop unrolled by 4 -- pays at 57..64 channels (7.9 -> 5.8 ms at C = 64), costs 10 % at 30
+// WIDE: in-channel loop unrolled by 4 -- pays at 57..64 channels (7.9 -> 5.8 ms at C = 64), costs 10 % at 30.
+// ITEMS: work items per thread; 38 row pairs x (conv_channels / 8) groups / 256 threads = 2 up to 104
+// channels, 3 up to 128.
+template <bool WIDE, int ITEMS = 2>
 __global__ __launch_bounds__(256) void b2h_fwd_f32_valu(const float* __restrict__ x,
                                                         float* __restrict__ y, int T,
                                                         int tiles_per_seq, ValuParams p,
@@ -66,8 +69,8 @@ __global__ __launch_bounds__(256) void b2h_fwd_f32_valu(const float* __restrict_
     if ((fa.flags & kPostMask) && fa.n_frames) nvalid = fa.n_frames[b];
 
     // work item = TWO consecutive rows x one 8-channel group (nrows is even in every layer): each
-    // pair of float4 weight reads feeds 16 FMAs.  <= 38 row pairs x 8 groups / 256 threads = 2 items.
-    constexpr int kMaxItems = 2;
+    // pair of float4 weight reads feeds 16 FMAs.  <= 38 row pairs x 8 (16) groups / 256 threads = 2 (3) items.
+    constexpr int kMaxItems = ITEMS;
 #pragma unroll 1
     for (int l = 0; l < 4; ++l) {
         const ValuLayer L = p.L[l];

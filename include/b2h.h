@@ -42,8 +42,10 @@ typedef enum b2h_status {
 /* Which hand-written kernel computes the four-layer stack. */
 typedef enum b2h_kernel {
     B2H_KERNEL_AUTO = 0,      /* the faster exact-fp32 kernel for the model's width: F32_MFMA, except
-                                 F32_VALU at conv_channels <= 8 and 33..39 (measured crossovers) */
-    B2H_KERNEL_F32_VALU = 1,  /* fp32 FMA on the vector ALU; any conv_channels <= 64 (cross-check kernel) */
+                                 F32_VALU at conv_channels <= 8 and 33..39 (measured crossovers) and above
+                                 64 (the only kernel there) */
+    B2H_KERNEL_F32_VALU = 1,  /* fp32 FMA on the vector ALU; any conv_channels <= 128 (cross-check kernel,
+                                 and the whole path for 65..128 channels) */
     B2H_KERNEL_F32_MFMA = 2,  /* exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32); any conv_channels <= 64
                                  (33..64: a one-wave-per-SIMD wide variant) */
     B2H_KERNEL_BF16_MFMA = 3, /* bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16); any
@@ -76,7 +78,8 @@ int b2h_device_count(void);
 /* Model lifetime ---------------------------------------------------------
  * Replaces ConvModel.__init__(conv_channels, activation, pos_emb)
  * (HandPoseModels.py:18-37).  `activation` must be "ReLU" (B2H_ERR_INVALID
- * otherwise, mirroring the ValueError at :34-37).  1 <= conv_channels <= 64.
+ * otherwise, mirroring the ValueError at :34-37).  1 <= conv_channels <= 128 (the reference's
+ * --conv-channels is a free integer, default 30: run.py:37); the matrix-core kernels cover 1..64.
  * The model is bound to the HIP device current at creation; b2h_forward / b2h_forward_fused (and
  * b2h_tenc_forward for its model) return B2H_ERR_INVALID when called while another device is current. */
 int b2h_create(int conv_channels, const char* activation, int pos_emb, b2h_model** out);

@@ -395,7 +395,7 @@ def main():
     # positional-embedding branch (requires T == 100)
     conv_case(hpm, "posemb_b2_t100", 2, 100, 30, True, "u01", 7)
     # other widths
-    for C in (8, 16, 32, 64):
+    for C in (8, 16, 32, 64, 128):
         conv_case(hpm, f"width_c{C}_b2_t50", 2, 50, C, False, "randn", 200 + C)
     # BASELINE.json config 2: batch=64, three input distributions
     for kind in ("randn", "u01", "u55"):

@@ -45,7 +45,7 @@ def test_create_error_paths_without_gpu():
     assert lib.b2h_create(30, b"Tanh", 0, ctypes.byref(h)) == _lib.ERR_INVALID
     assert b"ReLU" in lib.b2h_last_error()
     assert lib.b2h_create(0, b"ReLU", 0, ctypes.byref(h)) == _lib.ERR_INVALID
-    assert lib.b2h_create(65, b"ReLU", 0, ctypes.byref(h)) == _lib.ERR_INVALID
+    assert lib.b2h_create(129, b"ReLU", 0, ctypes.byref(h)) == _lib.ERR_INVALID
     if not torch.cuda.is_available():
         assert lib.b2h_device_count() == 0
         assert lib.b2h_create(30, b"ReLU", 0, ctypes.byref(h)) == _lib.ERR_NO_DEVICE

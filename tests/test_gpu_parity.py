@@ -42,8 +42,8 @@ def _model(rec, prec, dev):
 
 def _supported(rec, prec):
     """Every kernel runs every width 1..64 (33..64: the wide variants -- bf16 / f16 kernel_mfma16w.h,
-    f16x3 kernel_mfma3w.h, exact fp32 Geo32<true> in kernel_mfma.h)."""
-    return rec["C"] <= 64
+    f16x3 kernel_mfma3w.h, exact fp32 Geo32<true> in kernel_mfma.h); 65..128 is the VALU kernel's alone."""
+    return rec["C"] <= 64 or prec == "f32_valu"
 
 
 def _tol(rec, prec):
@@ -191,6 +191,42 @@ def test_wide_models_vs_oracle(C, prec, cuda_device):
             assert np.abs(yf - ref).max() <= 2 * TOL[prec] * 1280
             for b, n in enumerate(nf):
                 assert not yf[b, n:].any()
+
+
+@pytest.mark.parametrize("C", [65, 96, 104, 105, 128])
+def test_widths_above_64_run_on_the_valu_kernel(C, cuda_device):
+    """`--conv-channels` is a free integer (run.py:37).  65..128 channels: exact fp32 on the VALU kernel
+    (three work items per thread above 104), the matrix-core kernels refuse; checked against the oracle
+    on lengths around the 64-frame tile, with pos_emb, the fused transforms and batch independence."""
+    torch.manual_seed(2000 + C)
+    for pos_emb, lengths in ((False, [1, 17, 63, 64, 65, 130, 200]), (True, [100])):
+        m = hps.ConvModel(C, "ReLU", pos_emb).to(cuda_device).eval()          # precision "fp32" = AUTO
+        assert m.kernel_name() == "b2h_fwd_f32_valu"
+        state = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        g = torch.Generator().manual_seed(C)
+        for T in lengths:
+            x = torch.rand((3, T, 12, 2), generator=g) - 0.5
+            with torch.no_grad():
+                y = m(x.to(cuda_device))
+                big = m(torch.cat([x, torch.rand((200, T, 12, 2), generator=g) - 0.5]).to(cuda_device))
+            assert torch.equal(big[:3], y), (C, T)
+            ref = oracle.forward_from_state(x.numpy(), state, pos_emb=pos_emb)
+            assert np.abs(y.cpu().numpy() - ref).max() <= TOL["f32_valu"], (C, T)
+        if not pos_emb:
+            rng = np.random.default_rng(C)
+            body = (rng.random((4, 90, 12, 2), dtype=np.float32)) * np.array([1280.0, 720.0], np.float32)
+            nf = np.array([90, 1, 64, 33])
+            with torch.no_grad():
+                yf = m.forward_fused(torch.from_numpy(body).to(cuda_device), n_frames=nf, mask_tail=True).cpu().numpy()
+            inp, _ = oracle.preprocess(body, None)
+            ref = oracle.postprocess(oracle.forward_from_state(inp, state), 1280.0, nf)
+            assert np.abs(yf - ref).max() <= 2 * TOL["f32_valu"] * 1280
+    for prec in ("bf16", "f16", "f16x3", "f32_mfma"):
+        mm = hps.ConvModel(C, "ReLU", False, precision=prec).to(cuda_device).eval()
+        with torch.no_grad(), pytest.raises(RuntimeError, match="conv_channels"):
+            mm(torch.zeros((1, 8, 12, 2), device=cuda_device))
+    with pytest.raises(ValueError):
+        hps.ConvModel(129, "ReLU", False).to(cuda_device)(torch.zeros((1, 8, 12, 2)))
 
 
 def test_module_surface(cuda_device):
