@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box: randomized sweep of the ConvModel kernels against the oracle -- random width
-(1..64 on every kernel), pos_emb, batch, length, kernel and
+(1..64 on every kernel, up to 128 on the VALU kernel), pos_emb, batch, length, kernel and
 fused-transform flags; every case must meet the kernel's parity tolerance.
     python tools/stress_conv.py [seconds=120] [seed=0]"""
 import os, sys, time
@@ -24,7 +24,7 @@ worst = {k: 0.0 for k in TOL}
 while time.time() < t_end:
     prec = str(rng.choice(list(TOL)))
     pos_emb = bool(rng.random() < 0.15)
-    C = int(rng.integers(1, 65))
+    C = int(rng.integers(1, 129 if prec == "f32_valu" and rng.random() < 0.3 else 65))   # 65..128: the VALU kernel's alone
     T = 100 if pos_emb else int(rng.choice([rng.integers(1, 40), rng.integers(40, 260), rng.integers(260, 900)]))
     B = int(rng.choice([1, 2, 3, rng.integers(4, 40), rng.integers(40, 700)]))
     if B * T > 150000:
