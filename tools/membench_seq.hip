@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
         run("mixed seq head-pattern", W, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0>), g, b, 0, 0, x, y, nseq, sink); });
         run("mixed seq head-pattern, adjacent waves", W, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 1>), g, b, 0, 0, x, y, nseq, sink); });
     }
-    if (!quick) {   // cache policies on the kernel's own shape (8 waves per CU, head-pattern stores)
+    {   // cache policies on the kernel's own shape (8 waves per CU, head-pattern stores)
         const dim3 g(256), b(64 * 8);
         run("mixed head-pattern, stores sc0", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 1, 0>), g, b, 0, 0, x, y, nseq, sink); });
         run("mixed head-pattern, stores sc1", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 16, 0>), g, b, 0, 0, x, y, nseq, sink); });
@@ -108,6 +108,12 @@ int main(int argc, char** argv) {
         run("mixed head-pattern, loads sc1", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 0, 16>), g, b, 0, 0, x, y, nseq, sink); });
         run("mixed head-pattern, loads nt + stores sc1", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 1, 0, 16, 2>), g, b, 0, 0, x, y, nseq, sink); });
         run("mixed linear, loads nt", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 0, 0, 0, 2>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed linear, stores nt", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 0, 0, 2, 0>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed linear, stores sc0", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 0, 0, 1, 0>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed linear, stores sc1", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 0, 0, 16, 0>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed linear, stores sc0 nt", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 0, 0, 3, 0>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed linear, stores nt + loads nt", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 0, 0, 2, 2>), g, b, 0, 0, x, y, nseq, sink); });
+        run("mixed linear (default policy, again)", 8, rb + wb, [&] { hipLaunchKernelGGL((k_seq<3, 0, 0>), g, b, 0, 0, x, y, nseq, sink); });
     }
     for (int W : {1, 4, 8}) {
         const dim3 g(256), b(64 * W);
