@@ -73,6 +73,8 @@ def test_oracle_matches_reference_weighted_metric():
     assert abs(float(loss) - float(np.sum(r["per_seq"], dtype=np.float64))) <= 2e-6
     with pytest.raises(ValueError):
         oracle.weighted_l1(r["pred"], r["target"], r["scores"][:, :, :20], r["lengths"])
+    loss0, per0 = oracle.weighted_l1(r["pred"], r["target"], r["scores"], [60, 0, 33, 59, 17])
+    assert np.isnan(per0[1]) and np.isnan(loss0)            # mean of an empty slice, like torch
 
 
 @pytest.mark.gpu
@@ -85,6 +87,8 @@ def test_hip_weighted_metric_matches_reference(cuda_device):
     assert loss.dim() == 0 and loss.device.type == "cuda"
     assert abs(float(loss) - float(r["loss"])) <= 3e-6
     np.testing.assert_allclose(per.cpu().numpy(), r["per_seq"], rtol=3e-6)
+    _, per0 = hps.weighted_pose_l1(p, t, [60, 0, 33, 59, 17], sc, return_per_sequence=True)
+    assert torch.isnan(per0[1]) and not torch.isnan(per0[[0, 2, 3, 4]]).any()   # empty utterance -> NaN, like torch
     ones = torch.ones_like(sc)                              # unit confidences = B x maskedPoseL1
     assert abs(float(hps.weighted_pose_l1(p, t, r["lengths"], ones)) - 5 * float(hps.masked_pose_l1(p, t, r["lengths"]))) <= 5e-6
     with pytest.raises(RuntimeError):
