@@ -29,7 +29,22 @@ class LinearPositionalEmbedding(nn.Module):
         self.max_len = max_len
 
 
+PRECISION_NOTES = """precision (which hand-written kernel computes the four layers; max-abs error vs the reference's
+fp32 CPU forward, measured in tests/test_gpu_parity.py::test_error_vs_input_scale and tools/conv_precision_error.py):
+  "fp32"   exact fp32 on the matrix cores, <= 1.2e-7                  2.8 G frames/s   (default: the reference's arithmetic)
+  "f16x3"  fp32-grade: f16 hi+lo split operands, <= 1.2e-7            8.5 G frames/s   (needs |weights| < 65504)
+  "f16"    f16 operands, fp32 accumulate: 5e-5 on normalised keypoints, 1.2e-4 at N(0,1), 6e-4 at N(0,4^2);
+           meets north_star's <= 1e-3 gate up to |x| ~ 20          18 G frames/s
+  "bf16"   bf16 operands, fp32 accumulate: 3.7-5.0e-4 on normalised keypoints (|x| <~ 1), 1.05e-3 at N(0,1) --
+           i.e. it meets the <= 1e-3 gate only on inputs scaled like keypoints / 1280; `f16` runs at the SAME
+           speed and holds the gate on any such input, so prefer it unless bf16's exponent range is needed
+           (activations beyond 65504)                               18 G frames/s"""
+
+
 class ConvModel(nn.Module):
+    __doc__ = """ConvModel(conv_channels, activation, pos_emb, precision="fp32") -- the reference's constructor
+    (HandPoseModels.py:18-37) plus the kernel choice.\n\n""" + PRECISION_NOTES
+
     def __init__(self, conv_channels, activation, pos_emb, precision="fp32"):
         super().__init__()
         if pos_emb:

@@ -11,6 +11,7 @@ prints (traintest.py:27-28,139).
 import ctypes
 
 import torch
+import torch.nn as nn
 
 from . import _lib
 
@@ -64,3 +65,19 @@ def weighted_pose_l1(prediction, target, lengths, scores, return_per_sequence=Fa
 def l1_to_pixels(loss, num_joints=21, upsample=1280):
     """L12Pixels (steps/utils.py:291-299): loss / num_joints * upsample."""
     return loss / num_joints * upsample
+
+
+class maskedPoseL1(nn.Module):  # noqa: N801 -- the reference's class name (steps/utils.py:413-428)
+    """`criterion = maskedPoseL1()` as traintest.py:36-38 builds it; `criterion(prediction, target, lengths)`
+    runs the HIP reduction.  Inference / evaluation only (no autograd)."""
+
+    def forward(self, prediction, target, lengths):
+        return masked_pose_l1(prediction, target, lengths)
+
+
+class poderatedPoseL1(nn.Module):  # noqa: N801 -- the reference's class name (steps/utils.py:431-452)
+    """`criterion = poderatedPoseL1()` (`--loss confL1`, traintest.py:39-40);
+    `criterion(prediction, target, lengths, scores)`."""
+
+    def forward(self, prediction, target, lengths, scores):
+        return weighted_pose_l1(prediction, target, lengths, scores)

@@ -38,13 +38,21 @@ def test_one_json_line_with_the_contract_keys(cuda_device):
     assert d["unit"] == "frames/s" and d["data"] == "synthetic" and d["dtype"] == "bf16"
     assert d["value"] > 1e8 and abs(d["value"] - 2048 * 200 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["config"]["preconditioning_steps"] == 200     # untimed, disclosed; --precondition 0 turns it off
+    # the driver's protocol exactly: W warmup steps are the only launches before the K timed ones
+    assert d["config"]["preconditioning_steps"] == 0 and d["untimed_launches"] == 1
+    vs = d["value_sustained"]                               # the settled-stream rate, beside `value`, never as it
+    assert vs["value"] > 1e8 and vs["untimed_launches_before"] == 1 + 4 + 200
+    anyin = d["value_le_1e-3_any_input"]                    # the precision that meets north_star's gate on any input
+    assert anyin["precision"] == "f16" and anyin["value"] == d["kernels"]["f16"]["frames_per_s"]
     assert len(d["config"]["gpus"]) == 1 and d["config"]["gpus"][0]["pci"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "traffic" in rf
     _check_roofline(rf)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "frames/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    # fixed protocol: every thread count's rate is in the line, `value` is the best of them, load average beside it
+    assert cb["value"] == max(cb["rates_by_threads"].values()) and str(cb["cores"]) in cb["rates_by_threads"]
+    assert "1" in cb["rates_by_threads"] and cb["loadavg_1m_before"] >= 0 and cb["host_cores_available"] >= 1
     # every precision of the path is graded on the same shard and checked on the CPU sample
     assert set(d["kernels"]) == {"bf16", "f16", "f16x3", "f32_mfma"}
     for prec, rec in d["kernels"].items():
@@ -81,9 +89,10 @@ def test_self_launch_two_ranks_rehearsal(cuda_device):
     assert "cpu_baseline" not in d            # rank 0 at N = 1 only
     # the hand-back is a secondary figure: if it outlives its budget the line is still printed, with
     # `value` / `roofline` intact and the failure named in the `gather` object
+    # ... and the exit code says so too (3 = `value` stands, the hand-back measurement failed)
     r = subprocess.run(base + ["--backend", "gloo", "--gather-budget", "0.2"], capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.returncode == 3, (r.returncode, r.stderr[-3000:])
     lines = r.stdout.splitlines()
     assert len(lines) == 1, r.stdout[:2000]
     d2 = json.loads(lines[0])
@@ -112,6 +121,85 @@ def test_self_launch_propagates_rank_failure():
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "self-launch" in r.stderr and "torch.distributed.run" in r.stderr and "MI355X" in r.stderr
+
+
+def _guard_worker(rank, world, port, mode, out_dir):
+    """One rank of a SecondaryGuard scenario.  The store is a plain TCPStore (what torch.distributed's
+    rendezvous gives bench.py); no collective backend is involved -- in the scenarios below the
+    'collective' is a rank that waits for a peer that never comes."""
+    import time
+    from datetime import timedelta
+
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    store = dist.TCPStore("127.0.0.1", port, world, is_master=(rank == 0), timeout=timedelta(seconds=60))
+
+    def emit(reason):
+        with open(os.path.join(out_dir, "line.json"), "w") as f:
+            json.dump({"value": 1.0, "gather": {"error": reason}}, f)
+
+    def phase():
+        if mode == "peer_raises" and rank == 1:
+            time.sleep(0.3)
+            raise RuntimeError("NCCL error: unhandled system error (injected)")
+        if mode == "root_raises" and rank == 0:
+            raise RuntimeError("injected failure on root")
+        if mode in ("peer_raises", "root_raises", "hang"):
+            time.sleep(120)           # parked in a 'collective' the failing rank never joins
+        return {"ok": rank}
+
+    g = bench.SecondaryGuard(store, rank, world, budget=(1.0 if mode == "hang" else 60.0), emit=emit, poll=0.05, grace=10.0)
+    res = g.run(phase)
+    with open(os.path.join(out_dir, f"ok{rank}.json"), "w") as f:
+        json.dump(res, f)
+    if rank == 0:
+        time.sleep(0.5)               # the store's host leaves last
+
+
+@pytest.mark.parametrize("mode", ["ok", "peer_raises", "root_raises", "hang"])
+def test_secondary_guard_exit_codes(tmp_path, mode):
+    """The N > 1 hand-back measurement is secondary: a failure in ANY rank (exception on a peer, on root, or
+    a phase that outlives its budget) leaves the line -- written by rank 0 BEFORE any rank exits -- and every
+    rank's exit code is 3; a clean phase returns its result on every rank (bench.py: SecondaryGuard)."""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, mode, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(90)
+        assert p.exitcode is not None, "a rank is still alive"
+    codes = [p.exitcode for p in procs]
+    if mode == "ok":
+        assert codes == [0, 0]
+        assert json.load(open(tmp_path / "ok0.json")) == {"ok": 0} and json.load(open(tmp_path / "ok1.json")) == {"ok": 1}
+        assert not (tmp_path / "line.json").exists()
+    else:
+        assert codes == [3, 3], codes
+        err = json.load(open(tmp_path / "line.json"))["gather"]["error"]
+        assert {"peer_raises": "rank 1: RuntimeError: NCCL error", "root_raises": "rank 0: RuntimeError: injected",
+                "hang": "did not finish within 1 s"}[mode] in err
+        assert not (tmp_path / "ok0.json").exists() and not (tmp_path / "ok1.json").exists()
+
+
+def test_self_launch_exit_code_when_the_handback_failed(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` relays rank 0's line and turns a failed hand-back into exit code 3 (any other
+    rank failure keeps the launcher's code)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class R:
+        def __init__(self, rc, out):
+            self.returncode, self.stdout = rc, out.encode()
+
+    for rc, out, want in ((1, '{"value": 2.0, "gather": {"error": "rank 1: boom"}}\n', 3), (1, "", 1), (0, '{"value": 2.0}\n', 0)):
+        monkeypatch.setattr(bench.subprocess, "run", lambda *a, _r=R(rc, out), **k: _r)
+        with pytest.raises(SystemExit) as ei:
+            bench.self_launch(bench.parse(["--gpus", "2"]), ["--gpus", "2"])
+        assert ei.value.code == want
 
 
 def test_traffic_is_nulled_when_the_kernel_sources_changed(tmp_path, monkeypatch):

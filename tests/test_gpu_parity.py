@@ -525,3 +525,43 @@ def test_very_long_sequence_plain_and_fused(prec, cuda_device):
     ref = oracle.postprocess(oracle.forward_from_state(inp, rec["state"]), 1280.0, nf)
     assert np.abs(yf - ref).max() <= 2 * TOL[prec] * 1280
     assert not yf[1, 12345:].any()
+
+
+SCALE_SIGMAS = [0.25, 0.5, 1.0, 2.0, 4.0]
+
+
+def test_error_vs_input_scale(cuda_device):
+    """north_star's gate is <= 1e-3 max-abs vs the reference's fp32 forward.  bf16 meets it on inputs scaled
+    like normalised keypoints and exceeds it from sigma ~ 1 on (the documented BF16_RANDN_BOUND); this test
+    makes that a CURVE with a stated crossover instead of one fixture: N(0, sigma^2) inputs, sigma in
+    {0.25 ... 4}, every 16-bit precision and the fp32-grade ones against the fp32 oracle, seeded default
+    weights (the reference ships no checkpoint).  The curve is written to gpurun_out/ for DESIGN.md."""
+    import json
+    import os
+    rec = load_golden("cfg2_b64_t200_randn")
+    g = np.random.default_rng(7)
+    base = g.standard_normal((64, 200, 12, 2)).astype(np.float32)
+    curve = {p: [] for p in ("bf16", "f16", "f16x3", "f32_mfma")}
+    for sigma in SCALE_SIGMAS:
+        xs = base * np.float32(sigma)
+        ref = oracle.forward_from_state(xs, rec["state"])
+        xd = torch.from_numpy(xs).to(cuda_device)
+        for prec in curve:
+            with torch.no_grad():
+                y = _model(rec, prec, cuda_device)(xd).cpu().numpy()
+            curve[prec].append(float(np.abs(y - ref).max()))
+    print("max-abs error vs input sigma", SCALE_SIGMAS, json.dumps(curve))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "error_vs_input_scale.json"), "w") as f:
+            json.dump({"sigmas": SCALE_SIGMAS, "max_abs_err": curve, "inputs": "N(0, sigma^2), (64,200,12,2), seed 7",
+                       "weights": "golden cfg2 (seeded default init, C = 30)"}, f)
+    for i, sigma in enumerate(SCALE_SIGMAS):
+        # the 16-bit kernels' error is operand rounding, linear in the input scale once |x| dominates the bias
+        assert curve["f16"][i] <= 1e-3, (sigma, curve["f16"][i])                 # f16 holds the gate over the whole sweep
+        assert curve["f16x3"][i] <= 2e-5 * max(1.0, sigma) and curve["f32_mfma"][i] <= 2e-5 * max(1.0, sigma)
+        if sigma <= 0.5:
+            assert curve["bf16"][i] <= 1e-3, (sigma, curve["bf16"][i])           # normalised-keypoint scale: inside the gate
+        else:
+            assert curve["bf16"][i] <= BF16_RANDN_BOUND * sigma, (sigma, curve["bf16"][i])
+    assert curve["bf16"][SCALE_SIGMAS.index(1.0)] > curve["f16"][SCALE_SIGMAS.index(4.0)]   # f16 at 4 sigma beats bf16 at 1

@@ -137,6 +137,19 @@ def test_oracle_reproduces_reference_validate_loop():
             assert abs(np.mean(vals) - float(r[f"loss_{mname}_{lname}"])) <= 3e-6, (mname, lname)
 
 
+def test_validate_accepts_the_reference_call_forms():
+    """Argument handling of validate() (no GPU needed): args.loss wins, then the keyword, then the criterion's class."""
+    from types import SimpleNamespace
+
+    import hand_pose_sl_amd as hps
+    from hand_pose_sl_amd.evaluate import _loss_name
+    assert _loss_name(hps.maskedPoseL1(), None, None) == "L1" and _loss_name(hps.poderatedPoseL1(), None, None) == "confL1"
+    assert _loss_name(hps.maskedPoseL1(), SimpleNamespace(loss="confL1"), None) == "confL1"
+    assert _loss_name("confL1", None, None) == "confL1" and _loss_name(None, None, None) == "L1"
+    assert _loss_name(None, None, "confL1") == "confL1"
+    assert _loss_name(torch.nn.MSELoss(), None, None) == "MSELoss"      # refused by validate(): not an evaluation loss
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_hip_validate_loop_matches_reference(precision, cuda_device):
@@ -151,6 +164,15 @@ def test_hip_validate_loop_matches_reference(precision, cuda_device):
         for lname in ("L1", "confL1"):
             got = hps.validate(model, _batches(r), loss=lname)          # host batches, like the reference's loader
             assert abs(got - float(r[f"loss_{mname}_{lname}"])) <= 5e-6, (mname, lname, got)
+    # ... and called the way steps/traintest.py:136 calls it: validate(model, val_loader, criterion, device, args)
+    from types import SimpleNamespace
+    for mname, model in (("Conv", conv), ("TransformerEnc", tenc)):
+        for lname, crit in (("L1", hps.maskedPoseL1()), ("confL1", hps.poderatedPoseL1())):
+            got = hps.validate(model, _batches(r), crit, torch.device("cuda"), SimpleNamespace(model=mname, loss=lname))
+            assert abs(got - float(r[f"loss_{mname}_{lname}"])) <= 5e-6, (mname, lname, got)
+    assert hps.validate(conv, _batches(r), hps.poderatedPoseL1()) == hps.validate(conv, _batches(r), loss="confL1")
+    with pytest.raises(ValueError):      # traintest.py:199-200
+        hps.validate(conv, _batches(r), hps.maskedPoseL1(), None, SimpleNamespace(model="TextPoseTransformer", loss="L1"))
     val, pix = hps.validate(conv, _batches(r), return_pixels=True)
     assert abs(pix - val / 21 * 1280) <= 1e-9
     with pytest.raises(ValueError):
