@@ -30,6 +30,7 @@ OK, ERR_INVALID, ERR_SHAPE, ERR_NO_WEIGHTS, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPOR
 
 SYMBOLS = {
     "b2h_version": (ctypes.c_int, []),
+    "b2h_build_flags": (ctypes.c_int, []),
     "b2h_last_error": (ctypes.c_char_p, []),
     "b2h_device_count": (ctypes.c_int, []),
     "b2h_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(_vp)]),
@@ -82,6 +83,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library drift, fail loudly
         fn.restype = res
         fn.argtypes = args
+    flags = lib.b2h_build_flags()
+    if flags != 0 and os.environ.get("B2H_ALLOW_ABLATE") != "1":
+        # a timing-only development build (tools/ablate_*.sh) left in place of the product: wrong results by design
+        raise RuntimeError(f"{path} is a B2H_ABLATE={flags} development build (results wrong by construction); rebuild "
+                           f"with `python -m hand_pose_sl_amd.build --force`, or set B2H_ALLOW_ABLATE=1 to measure with it")
     _lib = lib
     return lib
 

@@ -117,6 +117,10 @@ struct DevBuf {
 
 } // namespace
 
+constexpr int kPoolSlots = 64;        // streams per model that get a chunk pool (Sched16); further streams run without
+constexpr int kPoolSlotBytes = 128;   // one cache line per slot
+constexpr int64_t kPoolMinChunks = 64; // chunks per workgroup from which a launch uses the pool
+
 struct b2h_model {
     int C = 0;
     int pos_emb = 0;
@@ -131,6 +135,12 @@ struct b2h_model {
     DevBuf mwbf_w[4], mwh_w[4], mw_bias[4]; // wide 16-bit kernel (33..64 channels): bf16 / f16 fragments, bias
     DevBuf mw3_w[4], mw32_w[4];             // wide f16x3 kernel: hi / lo f16 fragments; wide exact-fp32 kernel: fp32 fragments
     int num_cus = 256;
+    // Chunk pools of the persistent 16-bit kernel (kernel_mfma16.h, Sched16): one 128-byte slot per stream
+    // that has launched on this model, two words each (claim counter, finished workgroups), zero between
+    // launches.  Launches on one stream are ordered, so a slot is never shared by two running kernels.
+    DevBuf pools;
+    std::mutex pool_mu;
+    std::vector<hipStream_t> pool_streams;
     ValuParams vp;
     MfmaParams mp32, mp3, mpw_bf, mpw_h, mpw3, mpw32;
     float w_absmax = 0.f;         // largest |weight| or |bias| (NaN counts as inf): F16X3 needs < 65504
@@ -323,6 +333,10 @@ int pack_all(b2h_model* m, const HostWeights& hw) {
     int rc;
     if ((rc = m->mbf16_all.upload(ab.data(), ab.size()))) return rc;
     if ((rc = m->mf16_all.upload(ah.data(), ah.size()))) return rc;
+    if (!m->pools.p) { // once per model: a later weight replacement must not touch the words of a running launch
+        const std::vector<char> zeros((size_t)kPoolSlots * kPoolSlotBytes, 0);
+        if ((rc = m->pools.upload(zeros.data(), zeros.size()))) return rc;
+    }
     return B2H_OK;
 }
 
@@ -440,6 +454,8 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             }
         }
         const int cps = (int)((T + chunk_len - 1) / chunk_len);
+        // (equal chunks -- T = 200 as 100 + 100 instead of 112 + 88 -- measured 3.9 % SLOWER in f16x3 and 1.6 %
+        // in exact fp32, same-process A/B, profiles/r3_f16x3/ab_equal_chunks.txt: not done)
         const int64_t nchunks = B * cps;
         const int64_t grid = (nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
         if (grid > 0x7fffffff) return fail(B2H_ERR_SHAPE, "B*T too large for one launch");
@@ -482,12 +498,33 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             }
             const int cps16 = (int)((T + TT - 1) / TT);
             const unsigned grid16 = (unsigned)std::min<int64_t>(m->num_cus, nch);
+            if (nch >= 0x7fffffff) return fail(B2H_ERR_SHAPE, "B*T too large for one launch");
+            // Work distribution (Sched16): with >= 64 chunks per workgroup the last eighth of the launch is a
+            // pool the whole grid draws from (the XCDs do not finish together otherwise).  The pool's counter
+            // lives in this stream's slot; no slot (more than kPoolSlots streams) or a stream under capture
+            // (a graph may be replayed on any stream, concurrently with this one) means a launch without pool.
+            Sched16 sched{nullptr, 0xffffffffu};
+            const int64_t per_wg = nch / grid16;
+            if (per_wg >= kPoolMinChunks && m->pools.p) {
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+                if (cap == hipStreamCaptureStatusNone) {
+                    std::lock_guard<std::mutex> lock(m->pool_mu);
+                    size_t slot = 0;
+                    while (slot < m->pool_streams.size() && m->pool_streams[slot] != st) ++slot;
+                    if (slot == m->pool_streams.size() && slot < (size_t)kPoolSlots) m->pool_streams.push_back(st);
+                    if (slot < (size_t)kPoolSlots) {
+                        sched.pool = reinterpret_cast<unsigned*>(static_cast<char*>(m->pools.p) + slot * kPoolSlotBytes);
+                        sched.kstatic = (unsigned)(per_wg - per_wg / 8);
+                    }
+                }
+            }
             const bool fused = fa.flags != 0;
             const bool bf = (k == B2H_KERNEL_BF16_MFMA);
             const void* wp = bf ? m->mbf16_all.p : m->mf16_all.p;
 #define B2H_LAUNCH16(PR, FU)                                                                          \
-    hipLaunchKernelGGL((b2h_fwd_mfma16<PR, FU>), dim3(grid16), dim3(64 * kWaves16), kLds16, st, x, y, \
-                       (int)T, cps16, TT, nch, wp, m->pos_emb, fa)
+    hipLaunchKernelGGL((b2h_fwd_mfma16<PR, FU>), dim3(grid16), dim3(64 * kWaves16), kLdsAlloc16, st, x, y, \
+                       (int)T, cps16, TT, nch, wp, m->pos_emb, fa, sched)
             if (bf && !fused) B2H_LAUNCH16(PREC_BF16, false);
             else if (bf) B2H_LAUNCH16(PREC_BF16, true);
             else if (!fused) B2H_LAUNCH16(PREC_F16, false);
@@ -782,6 +819,7 @@ int b2h_tenc_forward_fused(b2h_tenc* m, const float* body, float* y, int64_t B, 
 extern "C" {
 
 int b2h_version(void) { return B2H_VERSION; }
+int b2h_build_flags(void) { return B2H_ABLATE; }
 
 const char* b2h_last_error(void) { return g_err.c_str(); }
 

@@ -10,7 +10,8 @@
 //     16384 s_memtime stamps of one workgroup's phases (tools/chain_stamps.py);
 //   f16x3 conv kernel: 32768 s_memtime stamps of one wave's phases (tools/conv3_stamps.py),
 //     64 one weight fragment per layer instead of 20-30 (prices the per-chunk weight reloads from L2),
-//     128 no input loads.
+//     128 no input loads;
+//   persistent 16-bit conv kernel: 65536 s_memtime stamps of one workgroup's phases (tools/conv16_stamps.py).
 #pragma once
 #ifndef B2H_ABLATE
 #define B2H_ABLATE 0
@@ -26,6 +27,26 @@ __device__ unsigned long long g_conv3_dbg[4 * 16];
     } while (0)
 #else
 #define B2H_STAMP3(cx, k) do { } while (0)
+#endif
+
+// persistent 16-bit conv kernel: 65536 s_memtime stamps of ONE workgroup's eight waves at the phase
+// boundaries of their first 32 chunks (tools/conv16_stamps.py): [wave][chunk][8]
+#if B2H_ABLATE & 65536
+__device__ unsigned long long g_conv16_dbg[8 * 32 * 8];
+#define B2H_STAMP16(wave, lane, it, k)                                                                      \
+    do {                                                                                                    \
+        if (blockIdx.x == gridDim.x / 2 && (lane) == 0 && (it) >= 40 && (it) < 72)                          \
+            g_conv16_dbg[((wave) * 32 + (int)((it) - 40)) * 8 + (k)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
+// ... and s_memrealtime (100 MHz, chip-wide) at every wave's entry and exit plus its chunk count: [wg][wave][3]
+__device__ unsigned long long g_conv16_span[256 * 8 * 3];
+#define B2H_SPAN16(wave, lane, slot, val)                                                                   \
+    do {                                                                                                    \
+        if ((lane) == 0 && blockIdx.x < 256) g_conv16_span[(blockIdx.x * 8 + (wave)) * 3 + (slot)] = (val); \
+    } while (0)
+#else
+#define B2H_STAMP16(wave, lane, it, k) do { } while (0)
+#define B2H_SPAN16(wave, lane, slot, val) do { } while (0)
 #endif
 
 #if B2H_ABLATE & 16384

@@ -11,3 +11,11 @@ extern "C" int b2h_debug_conv3_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(b2h::g_conv3_dbg), 4 * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
 }
 #endif
+#if B2H_ABLATE & 65536
+extern "C" int b2h_debug_conv16_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(b2h::g_conv16_dbg), 8 * 32 * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
+}
+extern "C" int b2h_debug_conv16_spans(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(b2h::g_conv16_span), 256 * 8 * 3 * sizeof(unsigned long long)) == hipSuccess ? 0 : -4;
+}
+#endif

@@ -38,7 +38,8 @@ constexpr int kWLayerOff16[4] = {0, 10 * kWFrag16, 20 * kWFrag16, 30 * kWFrag16}
 constexpr int kWBytes16 = 45 * kWFrag16;           // 46080
 constexpr int kBiasOff16[4] = {kWBytes16, kWBytes16 + 128, kWBytes16 + 256, kWBytes16 + 384};
 constexpr int kPacked16 = kWBytes16 + 9 * 64;      // + bias [L][mt][q][4] fp32 = 46656
-constexpr int kLds16 = kPacked16 + kWaves16 * kWaveLds16; // 161344 <= 163840
+constexpr int kLds16 = kPacked16 + kWaves16 * kWaveLds16; // 161344; + 16 for the chunk queue <= 163840
+constexpr int kLdsAlloc16 = kLds16 + 16;
 constexpr int kChunkWhole16 = 208;                 // a sequence up to this long is one chunk
 constexpr int kChunkSplit16 = 192;                 // longer sequences: chunks of 192 (+-8 halo)
 constexpr int kInRegs = 20;                        // ceil(208 * 6 / 64) float4 per lane (<= 208 input frames)
@@ -66,10 +67,15 @@ struct Geom16 {
     int in_lo, nf4;  // first input frame, number of float4 to load
 };
 
+// (chunk indices fit 32 bits: the host refuses launches with 2^31 chunks or more, and a whole-sequence
+// chunking -- every T <= 208 -- needs no division at all; the 64-bit one cost ~150 scalar instructions
+// per chunk)
 __device__ __forceinline__ Geom16 geom16(int64_t chunk, int cps, int TT, int T) {
     Geom16 g;
-    g.seq = chunk / cps;
-    const int c = (int)(chunk - g.seq * cps);
+    const unsigned ch = (unsigned)chunk;
+    const unsigned sq = cps == 1 ? ch : ch / (unsigned)cps;
+    g.seq = sq;
+    const int c = (int)(ch - sq * (unsigned)cps);
     g.s = c * TT;
     g.e = min(g.s + TT, T);
     g.in_lo = max(g.s - kHalo, 0);
@@ -374,24 +380,51 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
     }
 }
 
+// Work distribution of one launch (filled by the host, b2h_api.hip).  Workgroup b (of G) owns the STATIC
+// chunks b + G k, k < kstatic; the chunks [G kstatic, nchunks) form a POOL shared by the whole grid and
+// claimed one at a time from `pool` (a device word that is 0 at launch; pool[1] counts finished workgroups,
+// and the last one to finish resets both for the next launch on the same stream).  pool == nullptr: no pool,
+// kstatic is unbounded and every chunk is static (small launches, launches under stream capture).
+struct Sched16 {
+    unsigned* pool;
+    unsigned kstatic;
+};
+
 template <int PREC, bool FUSED>
 __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     const float* __restrict__ x, float* __restrict__ y, int T, int cps, int TT, int64_t nchunks,
-    const void* __restrict__ wpacked, int pos_emb, FusedArgs fa) {
+    const void* __restrict__ wpacked, int pos_emb, FusedArgs fa, Sched16 sched) {
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     // weights + biases of all four layers: one copy per workgroup
     for (int i = threadIdx.x; i < kPacked16 / 16; i += 64 * kWaves16)
         reinterpret_cast<uint4*>(smem16)[i] = reinterpret_cast<const uint4*>(wpacked)[i];
+    // Chunks are CLAIMED, not dealt.  (1) Inside a workgroup: its waves draw the workgroup's static chunks in
+    // order from a counter in LDS instead of each taking every eighth one.  The two waves of a SIMD do not run
+    // at the same speed -- the scheduler arbitrates by age, and tools/conv16_stamps.py shows waves 4-7 needing
+    // 1.55x the cycles of waves 0-3 per chunk -- so with a static split the older waves ran out of work at
+    // 77 % of the kernel and left each SIMD to one wave.  (2) Across workgroups: the XCDs do not run at the
+    // same speed either (workgroup end times differed by 7 %, by blockIdx % 8), so the last eighth of the
+    // launch is a pool that all workgroups draw from once their static share is gone.  A claim is made two
+    // chunks ahead (its answer is needed when the chunk after the next one is prefetched), so neither the LDS
+    // atomic nor the global one is ever waited for.  Which wave computes a chunk never changes its result.
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    lds_u32* const queue = (lds_u32*)(smem16 + kLds16);
+    if (threadIdx.x == 0) {
+        queue[0] = 2 * kWaves16; // the first sixteen are dealt: wave w starts with chunks w and w + 8
+        queue[1] = 0;            // waves of this workgroup that are done (pool launches)
+    }
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     char* lds = smem16 + kPacked16 + wave * kWaveLds16;
-    const int64_t stride = (int64_t)gridDim.x * kWaves16;
-    // consecutive chunks -> different CUs, so small batches spread over the chip (taking 8
-    // consecutive chunks per workgroup instead measured the same on a full stream)
-    int64_t chunk = blockIdx.x + (int64_t)gridDim.x * wave;
-    if (chunk >= nchunks) return;
+    const int64_t pool_base = (int64_t)gridDim.x * sched.kstatic; // first pool chunk (unused without a pool)
+    auto chunk_of = [&](unsigned k) { return blockIdx.x + (int64_t)gridDim.x * k; };
+    [[maybe_unused]] int64_t it = 0;   // chunks this wave has done (development stamps only)
+    int64_t chunk = chunk_of(wave);
+    if (chunk >= nchunks) return;     // (never with a pool: the host enables it for >= 64 chunks per workgroup)
+    int64_t next = chunk_of(wave + kWaves16);
+    B2H_SPAN16(wave, lane, 0, __builtin_amdgcn_s_memrealtime());
 
     auto src_of = [&](const Geom16& gg) { return x + (gg.seq * (int64_t)T + gg.in_lo) * kInCh; };
     Fused16 fu;
@@ -409,34 +442,73 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     issue_loads16(R, src_of(g), g.nf4 * 16, lane);
     convert16<PREC, FUSED>(R, Q, src_of(g), g.nf4, lane, fu);
     while (true) {
+        B2H_STAMP16(wave, lane, it, 0);
+        // claim the chunk after the next one: from the workgroup's share ...
+        unsigned kn = 0;
+        if (lane == 0) kn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         commit16<PREC>(Q, lds, g, T, lane, pos_emb);
-        const int64_t next = chunk + stride;
+        kn = __builtin_amdgcn_readfirstlane(kn);
+        // ... or, once that is used up, from the grid's pool.  The atomic is issued BEFORE the prefetch loads, so
+        // the wait that the loads need anyway (pin_loads16, after layer 2) covers it: vmcnt counts in order.
+        // (asm: hipcc's atomic optimizer wraps a __hip_atomic_fetch_add in a wave reduction whose readfirstlane
+        // waits for the answer on the spot -- vmcnt(0) here, i.e. for every store of the previous chunk; for
+        // the LDS claim above that wait is ~100 cycles and measured nothing)
+        const bool pooled = kn >= sched.kstatic;
+        unsigned pv = 0;
+        if (pooled && lane == 0)
+            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(pv) : "v"(0u), "v"(1u), "s"(sched.pool));
         const bool more = next < nchunks;
         // prefetch the next chunk; unconditional (an empty buffer when nothing is left)
         // so that the register lifetimes below do not depend on control flow
         const Geom16 gn = more ? geom16(next, cps, TT, T) : g;
         const int nf4n = more ? gn.nf4 : 0;
+        B2H_STAMP16(wave, lane, it, 1);
         issue_loads16(R, src_of(gn), nf4n * 16, lane); // flies under layers 1-2
         float* yseq = y + g.seq * (int64_t)T * kOutCh;
         int nvalid = T;
         if constexpr (FUSED)
             if (fu.mask) nvalid = (int)min((int64_t)T, max((int64_t)0, fa.n_frames[g.seq]));
+        B2H_STAMP16(wave, lane, it, 2);
         layer16p<PREC, 0, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
+        B2H_STAMP16(wave, lane, it, 3);
         layer16p<PREC, 1, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
+        B2H_STAMP16(wave, lane, it, 4);
         // The prefetch has had two layers to land.  Wait for it HERE -- the only vector-memory
-        // operations still in flight are those loads and the previous chunk's (older) stores,
-        // so vmcnt(0) does not wait for anything younger -- and cast it to 16 bit now (80 -> 40
-        // registers before the wide head).  The asm operands pin both the wait and the cast to
+        // operations still in flight are those loads (with the pool claim before them) and the previous
+        // chunk's (older) stores, so vmcnt(0) does not wait for anything younger -- and cast it to 16 bit
+        // now (80 -> 40 registers before the wide head).  The asm operands pin both the wait and the cast to
         // this point: left alone, hipcc sinks the cast below the head and its wait then also
         // drains this chunk's 52 output stores.
         pin_loads16(R);
+        asm volatile("" : "+v"(pv)); // the claim's answer is read after that wait, never before
+        const int64_t next2 = pooled ? pool_base + __builtin_amdgcn_readfirstlane(pv) : chunk_of(kn);
+        B2H_STAMP16(wave, lane, it, 5);
         convert16<PREC, FUSED>(R, Q, src_of(gn), nf4n, lane, fu);
         pin_regs16(Q);
         layer16p<PREC, 2, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
+        B2H_STAMP16(wave, lane, it, 6);
         layer16p<PREC, 3, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
-        if (!more) break;
+        B2H_STAMP16(wave, lane, it, 7);
+        if (!more) break; // claims only grow: next2 is past the end as well
         chunk = next;
+        next = next2;
+        ++it;
         g = gn;
+    }
+    B2H_SPAN16(wave, lane, 1, __builtin_amdgcn_s_memrealtime());
+    B2H_SPAN16(wave, lane, 2, (unsigned long long)(it + 1));
+    // Pool launches: the last wave of the last workgroup to finish leaves the pool words at 0 for the next
+    // launch on this stream (every claim of every other wave has returned by then: a wave counts itself done
+    // only after its last claim was consumed).
+    if (sched.pool != nullptr && lane == 0) {
+        const unsigned w = __hip_atomic_fetch_add(queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (w == kWaves16 - 1) {
+            const unsigned d = __hip_atomic_fetch_add(sched.pool + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == gridDim.x - 1) {
+                __hip_atomic_store(sched.pool, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sched.pool + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 

@@ -71,6 +71,10 @@ typedef struct b2h_model b2h_model; /* opaque; owns the packed device weights */
 /* Library / device ------------------------------------------------------- */
 
 int b2h_version(void);
+/* 0 for the shipped library.  Non-zero = a development build with parts of a kernel removed or instrumented
+ * (csrc/dev/b2h_dev.h, B2H_ABLATE): its results may be WRONG by construction; the Python binding refuses to
+ * load such a library unless B2H_ALLOW_ABLATE=1 is set (the measurement scripts under tools/ set it). */
+int b2h_build_flags(void);
 const char* b2h_last_error(void);
 /* Number of visible HIP devices whose arch is gfx950 (0 when none). */
 int b2h_device_count(void);

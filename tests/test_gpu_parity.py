@@ -563,5 +563,56 @@ def test_error_vs_input_scale(cuda_device):
         if sigma <= 0.5:
             assert curve["bf16"][i] <= 1e-3, (sigma, curve["bf16"][i])           # normalised-keypoint scale: inside the gate
         else:
-            assert curve["bf16"][i] <= BF16_RANDN_BOUND * sigma, (sigma, curve["bf16"][i])
+            # operand rounding scales with the input: measured 1.08e-3 / 2.32e-3 / 4.31e-3 at sigma 1 / 2 / 4
+            assert curve["bf16"][i] <= 1.2e-3 * sigma, (sigma, curve["bf16"][i])
     assert curve["bf16"][SCALE_SIGMAS.index(1.0)] > curve["f16"][SCALE_SIGMAS.index(4.0)]   # f16 at 4 sigma beats bf16 at 1
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_claimed_chunks_pool_launches(prec, cuda_device):
+    """The persistent 16-bit kernel's work distribution (kernel_mfma16.h, Sched16): from 64 chunks per workgroup
+    on, the last eighth of a launch is a pool that every workgroup claims from, its counter in a per-stream
+    slot that the kernel itself leaves at zero.  Which wave computes a chunk must never show in the result:
+    a pool launch == the same sequences run in small launches (no pool, LDS queue only) == a launch captured
+    in a graph (no pool: a graph may replay on any stream), bit for bit; back-to-back pool launches on one
+    stream and concurrent ones on two streams (two slots) repeat it exactly."""
+    rec = load_golden("cfg2_b64_t200_u55")
+    m = _model(rec, prec, cuda_device)
+    ncu = torch.cuda.get_device_properties(cuda_device).multi_processor_count
+    S = 64 * ncu + 37                                  # >= 64 chunks per workgroup, not a multiple of anything
+    g = torch.Generator().manual_seed(33)
+    x = (torch.rand((S, 200, 12, 2), generator=g) - 0.5).to(cuda_device)
+    with torch.no_grad():
+        y_pool = m(x)
+        y_small = torch.cat([m(x[a:a + 4000]) for a in range(0, S, 4000)])          # 15 chunks per workgroup: no pool
+        assert torch.equal(y_pool, y_small)
+        idx = [0, 1, 4000, S - 1]
+        ref = oracle.forward_from_state(x[idx].cpu().numpy(), rec["state"])
+        assert np.abs(y_pool[idx].cpu().numpy() - ref).max() <= TOL[prec]
+        for _ in range(4):                                                           # the pool words are back at zero
+            assert torch.equal(m(x), y_pool)
+        x2 = x.flip(0).contiguous()
+        y2 = m(x2)
+        assert torch.equal(y2, y_pool.flip(0))
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for _ in range(3):
+            with torch.cuda.stream(s1):
+                ya = m(x)
+            with torch.cuda.stream(s2):
+                yb = m(x2)
+            outs.append((ya, yb))
+        torch.cuda.synchronize()
+        for ya, yb in outs:
+            assert torch.equal(ya, y_pool) and torch.equal(yb, y2)
+        xs = x.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ys = m(xs)
+        for src, want in ((x2, y2), (x, y_pool)):
+            xs.copy_(src)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(ys, want)
+        assert torch.equal(m(x), y_pool)                                             # and a pool launch after the replays

@@ -4,9 +4,11 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$REPO"
+# whatever happens below, the shipped (B2H_ABLATE = 0) build is what is left in place
+trap 'B2H_ABLATE= python -m hand_pose_sl_amd.build --force > /dev/null 2>&1' EXIT
+export B2H_ALLOW_ABLATE=1   # hand_pose_sl_amd._lib refuses ablation builds without it
 for a in ${1:-0 256 512 1024 2048 4096 8192}; do
   B2H_ABLATE=$a python -m hand_pose_sl_amd.build --force > /dev/null 2>&1
   r=$(timeout -k 10 200 python tools/bench_tenc.py --quick 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.3f ms' % d['runs'][0]['ms'])")
   echo "ablate=$a : $r"
 done
-B2H_ABLATE= python -m hand_pose_sl_amd.build --force > /dev/null 2>&1
