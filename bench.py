@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # dense matrix peak per precision (MI355X_MICROARCH.md); f16x3 issues three f16 MFMAs per product
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16x3": 2500.0 / 3, "f32_mfma": 157.3, "f32_valu": 157.3, "fp32": 157.3}
 DTYPE = {"bf16": "bf16", "f16": "f16", "f16x3": "f16x3 (f16 hi+lo operands, fp32-grade)", "f32_mfma": "f32", "f32_valu": "f32", "fp32": "f32"}
-TRAFFIC_JSON = os.path.join("profiles", "r2_final", "traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r3_final", "traffic.json")
 TRAFFIC_SOURCES = [os.path.join("hand_pose_sl_amd", "csrc", f) for f in ("kernel_mfma16.h", "kernel_mfma.h", "b2h_common.h", "b2h_api.hip")]
 
 

@@ -32,7 +32,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n_seq, out_path):
+def _worker(rank, world, port, n_seq, out_path, chunk=2):
     import oracle
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,7 +50,7 @@ def _worker(rank, world, port, n_seq, out_path):
             assert y is None
         y_local = stream.run(x[lo:hi], n_seq, gather=False)
         assert y_local.shape[0] == hi - lo
-        y_pipe = stream.run_pipelined(x[lo:hi], n_seq, chunk=2)      # piecewise hand-back, same result
+        y_pipe = stream.run_pipelined(x[lo:hi], n_seq, chunk=chunk)  # piecewise hand-back, same result
         if rank == 0:
             assert torch.equal(y_pipe, y)
         else:
@@ -65,6 +65,20 @@ def test_gloo_world2_gather_equals_single_process(tmp_path, n_seq):
     import oracle
     out = str(tmp_path / "y.npy")
     mp.spawn(_worker, args=(2, _free_port(), n_seq, out), nprocs=2, join=True)
+    rec = load_golden("cfg2_b64_t200_u55")
+    ref = oracle.forward_from_state(rec["x"][:n_seq, :40], rec["state"])
+    assert np.array_equal(np.load(out), ref)
+
+
+@pytest.mark.parametrize("world,n_seq,chunk", [(3, 10, 3), (8, 13, 1), (8, 5, 2), (8, 64, 3)])
+def test_gloo_many_ranks_uneven_shards(tmp_path, world, n_seq, chunk):
+    """The 8-rank shape of the node the bench targets, rehearsed on CPU: root posts up to 7 grouped
+    receives per piece; shards are unequal (13 over 8 = 2,2,2,2,2,1,1,1), some ranks own nothing
+    (5 over 8), piece counts differ between ranks (chunk does not divide the shards), and a 3-rank
+    world with a piece length that divides nothing.  Gathered and pipelined results == one process."""
+    import oracle
+    out = str(tmp_path / "y.npy")
+    mp.spawn(_worker, args=(world, _free_port(), n_seq, out, chunk), nprocs=world, join=True)
     rec = load_golden("cfg2_b64_t200_u55")
     ref = oracle.forward_from_state(rec["x"][:n_seq, :40], rec["state"])
     assert np.array_equal(np.load(out), ref)
