@@ -67,38 +67,48 @@ __device__ __forceinline__ void layer16w(const ChunkCtx& cx, const MfmaParams& m
     }
     const int pin = 8 - 2 * L - cx.s;
     const int pout = pin - 2;
-    // swizzled byte offsets of this lane's tap rows and of its write-back row in tile 0; a tile step
-    // is 16 rows = 2048 B and leaves the swizzle term (P & 7) unchanged
-    // (chunk 4 + q of a row = chunk q's offset ^ 64, chunk 2q + 1 = chunk 2q's ^ 16: one register per tap)
-    int roff[kTaps];
+    // Fragment and write-back addresses as 32-bit LDS pointers of the tile the loop stands at (chunk 4 + q of
+    // a row sits at chunk q's offset ^ 64, which is +-64 depending on the row, so the second k-step cannot be
+    // an immediate: one XOR where it is read; likewise chunk 2q + 1 = chunk 2q's ^ 16).  A tile step is 16 rows = 2048 B and
+    // leaves the swizzle term (P & 7) unchanged, so the pointers advance once per TWO tiles, opaque to the
+    // compiler, and every access in between is register + immediate (round 2's loop re-derived all twenty
+    // fragment addresses per tile: two vector instructions each).
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) const vec8 lds_cvec8;
+    typedef __attribute__((address_space(3))) uint4 lds_u4;
+    lds_char* rp[kTaps]; // k-step 0; k-step 1 is this ^ 64, formed where it is used (a pointer per k-step spilled)
 #pragma unroll
-    for (int s = 0; s < kTaps; ++s) roff[s] = lds_offw(lo + cx.tcol + s - kPad + pin, cx.q);
-    const int woff = lds_offw(lo + cx.tcol + pout, 2 * cx.q);
+    for (int s = 0; s < kTaps; ++s) rp[s] = (lds_char*)(cx.lds + lds_offw(lo + cx.tcol + s - kPad + pin, cx.q));
+    lds_char* wp = (lds_char*)(cx.lds + lds_offw(lo + cx.tcol + pout, 2 * cx.q));
+    auto flip = [](lds_char* p, unsigned bits) { return (lds_char*)(uintptr_t)((unsigned)(uintptr_t)p ^ bits); };
+    int tq = lo + cx.tcol; // this lane's frame in the tile the loop stands at
     HeadStore<FUSED> hs;
     if constexpr (L == 3) hs.init(cx, lo);
 
-#pragma unroll 1
-    for (int m = 0; m < ntiles; ++m) {
-        const int tau = lo + 16 * m;
-        f32x4 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = bias[mt];
-#pragma unroll
-        for (int s = 0; s < kTaps; ++s)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const vec8 b = *reinterpret_cast<const vec8*>(cx.lds + ((roff[s] + m * (16 * kWideRowB)) ^ (64 * ks)));
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = P::mfma(A[mt][s][ks], b, acc[mt]);
-            }
+    // Fragments travel through a RING of five registers sets, four k-steps ahead of their use (4 x 4 MFMAs =
+    // 256 cycles, the LDS latency under load): the loop body is two tiles = 20 (layer 1: 10) k-steps, a
+    // multiple of five, so every ring slot is a register NAME.  A whole tile's fragments a tile ahead (40
+    // registers beside the 160 of the weights) spilled; five sets are 20.  Past a layer's last tile the ring
+    // reads rows nobody uses (LDS reads beyond the allocation return 0).
+    constexpr int NS = kTaps * KS, kDist = 4, kRing = 5;
+    static_assert((2 * NS) % kRing == 0, "ring slots must be static across the two-tile body");
+    vec8 Br[kRing];
+    f32x4 acc[MT];
+    auto frag = [&](int step, int tile) { // k-step `step` of the tile `tile` tiles past the pointers
+        const int s = step / KS, ks = step % KS;
+        return *(lds_cvec8*)((ks ? flip(rp[s], 64u) : rp[s]) + tile * (16 * kWideRowB));
+    };
+    // epilogue of the tile `k` tiles past the one the pointers stand at; `mask`: only a layer's LAST tile
+    // can hold frames >= T (the zero padding of the next layer)
+    auto epi = [&](int k, bool mask) {
         if constexpr (L < 3) {
             float v[16]; // channels 16q + 4mt + r = slot 4mt + r of this lane's two chunks
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[4 * mt + r] = relu_bits(acc[mt][r]);
-            if (tau + 16 > cx.T) { // only the tile that crosses the sequence end: frames >= T are padding
-                const bool inside = tau + cx.tcol < cx.T;
+            if (mask) {
+                const bool inside = tq + 16 * k < cx.T;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) v[j] = inside ? v[j] : 0.f;
             }
@@ -106,14 +116,49 @@ __device__ __forceinline__ void layer16w(const ChunkCtx& cx, const MfmaParams& m
             for (int hh = 0; hh < 2; ++hh) {
                 const uint4 o = {pack2<PREC>(v[8 * hh], v[8 * hh + 1]), pack2<PREC>(v[8 * hh + 2], v[8 * hh + 3]),
                                  pack2<PREC>(v[8 * hh + 4], v[8 * hh + 5]), pack2<PREC>(v[8 * hh + 6], v[8 * hh + 7])};
-                *reinterpret_cast<uint4*>(cx.lds + ((woff + m * (16 * kWideRowB)) ^ (16 * hh))) = o;
+                *(lds_u4*)((hh ? flip(wp, 16u) : wp) + k * (16 * kWideRowB)) = o;
             }
         } else {
-            hs.store(cx, acc, 0);
-            hs.off += 16 * kOutCh * 4;
-            hs.t0 += 16;
+            hs.store(cx, acc, k);
         }
+    };
+    auto advance2 = [&]() {
+#pragma unroll
+        for (int s = 0; s < kTaps; ++s) {
+            rp[s] += 2 * 16 * kWideRowB;
+            asm volatile("" : "+v"(rp[s]));
+        }
+        wp += 2 * 16 * kWideRowB;
+        asm volatile("" : "+v"(wp));
+        tq += 32;
+        if constexpr (L == 3) hs.advance2();
+    };
+    // the two-tile body: tiles k = 0, 1 past the pointers (`two` = false: only tile 0), masks for a last tile
+    auto body = [&](bool two, bool mask0, bool mask1) {
+#pragma unroll
+        for (int j = 0; j < 2 * NS; ++j) {
+            const int k = j / NS, jj = j % NS;
+            if (k == 1 && !two) break;
+            if (jj == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = bias[mt];
+            }
+            Br[(j + kDist) % kRing] = frag((j + kDist) % NS, (j + kDist) / NS); // slot of k-step j - 1: already issued
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = P::mfma(A[mt][jj / KS][jj % KS], Br[j % kRing], acc[mt]);
+            if (jj == NS - 1) epi(k, k == 0 ? mask0 : mask1);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < kDist; ++j) Br[j] = frag(j, 0);
+    int m = 0;
+#pragma unroll 1
+    for (; m + 2 < ntiles; m += 2) { // two tiles, neither the layer's last: no mask, no branch
+        body(true, false, false);
+        advance2();
     }
+    if (m + 1 < ntiles) body(true, false, true);
+    else body(false, true, false);
     if constexpr (L < 3) {
         if (hi == cx.T) { // rows T, T+1 of the next layer's input: zero unless a tile covered them
             const int covered = lo + 16 * ntiles;
