@@ -75,7 +75,7 @@ __device__ __forceinline__ void layer16w(const ChunkCtx& cx, const MfmaParams& m
     // fragment addresses per tile: two vector instructions each).
     typedef __attribute__((address_space(3))) char lds_char;
     typedef __attribute__((address_space(3))) const vec8 lds_cvec8;
-    typedef __attribute__((address_space(3))) uint4 lds_u4;
+    typedef __attribute__((address_space(3))) u32x4 lds_u4;
     lds_char* rp[kTaps]; // k-step 0; k-step 1 is this ^ 64, formed where it is used (a pointer per k-step spilled)
 #pragma unroll
     for (int s = 0; s < kTaps; ++s) rp[s] = (lds_char*)(cx.lds + lds_offw(lo + cx.tcol + s - kPad + pin, cx.q));
@@ -114,7 +114,7 @@ __device__ __forceinline__ void layer16w(const ChunkCtx& cx, const MfmaParams& m
             }
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const uint4 o = {pack2<PREC>(v[8 * hh], v[8 * hh + 1]), pack2<PREC>(v[8 * hh + 2], v[8 * hh + 3]),
+                const u32x4 o = {pack2<PREC>(v[8 * hh], v[8 * hh + 1]), pack2<PREC>(v[8 * hh + 2], v[8 * hh + 3]),
                                  pack2<PREC>(v[8 * hh + 4], v[8 * hh + 5]), pack2<PREC>(v[8 * hh + 6], v[8 * hh + 7])};
                 *(lds_u4*)((hh ? flip(wp, 16u) : wp) + k * (16 * kWideRowB)) = o;
             }
