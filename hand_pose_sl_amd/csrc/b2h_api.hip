@@ -556,7 +556,9 @@ struct b2h_tenc {
     TencBlob in_proj, out_proj;
     struct Layer {
         TencBlob q, k, v, attn_out, ff1, ff2;
+        TencBlob qkv_head[kTencHeads]; // rows of Q_h, K_h, V_h of in_proj_weight: the projection inside b2h_attn_qkv_h3
     };
+    int num_cus = 256;
     std::vector<Layer> layers;
 };
 
@@ -647,6 +649,7 @@ int b2h_tenc_create(int ninp, int nhead, int nhid, int nout, int nlayers, int ma
         return fail(B2H_ERR_NO_DEVICE, std::string("device is ") + p.gcnArchName + ", libb2h is built for gfx950 only");
     m->nlayers = nlayers;
     m->max_len = max_len;
+    m->num_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     m->layers.resize(nlayers);
     *out = m.release();
     return B2H_OK;
@@ -688,6 +691,9 @@ int b2h_tenc_load_weights(b2h_tenc* m, const float* const* tensors, int count, i
     constexpr int kChainLds = 2 * kStageBlobMax * (int)sizeof(float);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_tenc_chain<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_tenc_chain<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds));
+#define B2H_AQ_CAP(N) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(b2h_attn_qkv_h3<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    B2H_AQ_CAP(1) B2H_AQ_CAP(2) B2H_AQ_CAP(3) B2H_AQ_CAP(4) B2H_AQ_CAP(5) B2H_AQ_CAP(6) B2H_AQ_CAP(7) B2H_AQ_CAP(8)
+#undef B2H_AQ_CAP
     m->w_absmax = 0.f;
     for (int i = 1; i < count; ++i) m->w_absmax = absmax_of(h[i], m->w_absmax); // h[0] is the pe table (|pe| <= 1)
     int rc;
@@ -699,6 +705,15 @@ int b2h_tenc_load_weights(b2h_tenc* m, const float* const* tensors, int count, i
         if ((rc = pack_blob(L.q, h[o].data(), h[o + 1].data(), 0, D, D, nullptr, nullptr))) return rc;
         if ((rc = pack_blob(L.k, h[o].data(), h[o + 1].data(), D, D, D, nullptr, nullptr))) return rc;
         if ((rc = pack_blob(L.v, h[o].data(), h[o + 1].data(), 2 * D, D, D, nullptr, nullptr))) return rc;
+        for (int hd = 0; hd < kTencHeads; ++hd) { // [Q_h | K_h | V_h]: rows 32 hd .. of each third of in_proj_weight / bias
+            std::vector<float> wh((size_t)3 * kTencHd * D), bhd((size_t)3 * kTencHd);
+            for (int part = 0; part < 3; ++part)
+                for (int r = 0; r < kTencHd; ++r) {
+                    std::memcpy(&wh[((size_t)part * kTencHd + r) * D], &h[o][((size_t)part * D + hd * kTencHd + r) * D], D * 4);
+                    bhd[part * kTencHd + r] = h[o + 1][part * D + hd * kTencHd + r];
+                }
+            if ((rc = pack_blob(L.qkv_head[hd], wh.data(), bhd.data(), 0, 3 * kTencHd, D, nullptr, nullptr))) return rc;
+        }
         if ((rc = pack_blob(L.attn_out, h[o + 2].data(), h[o + 3].data(), 0, D, D, h[o + 8].data(), h[o + 9].data()))) return rc;
         if ((rc = pack_blob(L.ff1, h[o + 4].data(), h[o + 5].data(), 0, D, D, nullptr, nullptr))) return rc;
         if ((rc = pack_blob(L.ff2, h[o + 6].data(), h[o + 7].data(), 0, D, D, h[o + 10].data(), h[o + 11].data()))) return rc;
@@ -742,6 +757,54 @@ int tenc_launch(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T, con
     float* OC = XA + n * kTencD;
     float* QKV = OC + n * kTencD;
     int rc;
+    const bool h3 = m->kernel == B2H_TENC_F16X3;
+    if (h3) {
+        // Round 3: the Q, K, V projection runs inside the attention kernel (b2h_attn_qkv_h3), so only the residual
+        // stream and the attention output cross HBM between launches (2.5 KB per frame and layer -> 1.25 KB).
+        {   // src + pe -> pose2hidden_projection (HandPoseModels.py:167-169) -> residual stream
+            ChainArgs a{};
+            a.x = x; a.ldx = kInCh; a.kgroups0 = 2; a.kvalid = kInCh; a.pe = (const float*)m->pe.p; a.T = (int)T;
+            a.res = nullptr; a.n = n; a.nstages = 1;
+            a.flags = fa.flags & (kPreChest | kPreNorm); a.factor = fa.factor; a.Tseq = (int)T;
+            a.st[0] = stage_of(m, m->in_proj, ST_SET, XA, kTencD);
+            if ((rc = launch_chain(m, a, st))) return rc;
+        }
+        const int nt = (int)((T + 15) / 16);
+        // persistent: one workgroup per CU, bound to a head (blockIdx = 8 (4 slot + head) + xcd: 32 per sequence slot)
+        const unsigned grid = (unsigned)std::max(32, m->num_cus / 32 * 32);
+        const size_t qlds = (size_t)kQkvBlobBytes + 2 * ((size_t)2 * nt * 16 * kTencHd * 2 + (size_t)2 * kTencHd * kAttnVtRow * 2);
+        for (int l = 0; l < m->nlayers; ++l) { // torch.nn.TransformerEncoderLayer, post-norm, ReLU
+            auto& L = m->layers[l];
+            AttnQkvArgs qa{};
+            qa.x = XA; qa.out = OC; qa.T = (int)T; qa.B = B;
+            for (int hd = 0; hd < kTencHeads; ++hd) qa.blob[hd] = (const float*)L.qkv_head[hd].buf16.p;
+            switch (nt) {
+#define B2H_AQ(N) case N: hipLaunchKernelGGL(b2h_attn_qkv_h3<N>, dim3(grid), dim3(64 * N), qlds, st, qa); break;
+                B2H_AQ(1) B2H_AQ(2) B2H_AQ(3) B2H_AQ(4) B2H_AQ(5) B2H_AQ(6) B2H_AQ(7) B2H_AQ(8)
+#undef B2H_AQ
+                default: return fail(B2H_ERR_SHAPE, "TransformerEnc: T > 128");
+            }
+            // out_proj +res LN1 -> linear1 ReLU -> linear2 +res LN2 -> residual stream | hidden2pose (:171)
+            ChainArgs a{};
+            a.x = OC; a.ldx = kTencD; a.kgroups0 = 8; a.kvalid = kTencD; a.pe = nullptr; a.T = 1;
+            a.res = XA; a.n = n;
+            a.st[0] = stage_of(m, L.attn_out, ST_RESLN_GLOBAL, nullptr, kTencD);
+            a.st[1] = stage_of(m, L.ff1, ST_RELU, nullptr, kTencD);
+            if (l + 1 < m->nlayers) {
+                a.st[2] = stage_of(m, L.ff2, ST_RESLN_REG, XA, kTencD); // the next layer's input and residual
+                a.nstages = 3;
+            } else {
+                a.st[2] = stage_of(m, L.ff2, ST_RESLN_REG, nullptr, kTencD);
+                a.st[3] = stage_of(m, m->out_proj, ST_STORE, y, kOutCh);
+                a.nstages = 4;
+                a.flags = fa.flags & (kPostDenorm | kPostMask); a.factor = fa.factor; a.n_frames = fa.n_frames;
+            }
+            a.Tseq = (int)T;
+            if ((rc = launch_chain(m, a, st))) return rc;
+        }
+        HIP_TRY(hipGetLastError());
+        return B2H_OK;
+    }
     {   // src + pe -> pose2hidden_projection (HandPoseModels.py:167-169) -> layer 0's Q, K, V
         ChainArgs a{};
         a.x = x; a.ldx = kInCh; a.kgroups0 = 2; a.kvalid = kInCh; a.pe = (const float*)m->pe.p; a.T = (int)T;
@@ -757,7 +820,6 @@ int tenc_launch(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T, con
         auto& L = m->layers[l];
         const int nt = (int)((T + 15) / 16);
         const dim3 ag((unsigned)(B * kTencHeads)), ab(64 * nt);
-        const bool h3 = m->kernel == B2H_TENC_F16X3;
         // fp32: K and V rows padded to kAttnRow floats; f16x3: K hi/lo [keys][32] + V^T hi/lo [32][kAttnVtRow]
         const size_t alds = h3 ? ((size_t)2 * nt * 16 * kTencHd + (size_t)2 * kTencHd * kAttnVtRow) * 2
                                : (size_t)nt * 16 * kAttnRow * 8;

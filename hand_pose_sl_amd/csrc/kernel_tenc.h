@@ -399,6 +399,184 @@ __device__ __forceinline__ f32x4 chain_ld(__amdgpu_buffer_rsrc_t rs, uint32_t of
 }
 
 
+// ---- Q, K, V projection + self-attention in one kernel (B2H_TENC_F16X3) ---------------------------
+// Round 3.  In the two-kernel form above the chain wrote Q, K, V (1 536 B per frame and layer) for the
+// attention kernel to read back: 60 % of the path's HBM traffic, on kernels that sit on their HBM floor.
+// Here the projection lives where its result is used: a workgroup is bound to one HEAD for the whole
+// launch -- its 96 x 128 slice of in_proj_weight (rows of Q_h, K_h, V_h; f16 hi + lo fragments, 48 KB)
+// is copied into LDS once -- and walks over sequences: wave w owns frames 16w .. 16w+15 of the sequence,
+//     x rows (residual stream, 512 B per frame)  --split-->  [Q_h | K_h | V_h] = W_h . x + b_h     (72 MFMAs)
+//     Q_h stays in registers: with the chain's k-slot order (slot (q, j) = dim 16(j>>2) + 4q + (j&3)) a lane's
+//         eight accumulators ARE its query fragment; K_h goes to LDS as the lane's one 16-byte chunk of its
+//         key row in the same slot order, V_h as V^T[dim][key slot] like b2h_attn_mfma_h3 stores it
+//     barrier, then scores / softmax / P.V exactly as in b2h_attn_mfma_h3.
+// K and V are double-buffered (sequence i + 1 is projected while slower waves still attend to sequence i:
+// one barrier per sequence), the next sequence's x rows are requested before this one's MFMAs.  Only the
+// residual stream (read) and the attention output (written) cross HBM: 1 KB per frame and layer instead of
+// 2 KB here + 1.5 KB of Q, K, V stores in the chain.  The four head-workgroups of a sequence list sit on
+// one XCD (blockIdx = 8 * (4 * slot + head) + xcd), so three of their four reads of a row are L2 hits.
+// hi = f16(v) packed two per instruction, residual v - hi as one mixed-precision FMA per value, lo = f16(residual):
+// 16 vector instructions for 8 values (the scalar casts cost twice that; see split8 in kernel_mfma3.h)
+__device__ __forceinline__ void tenc_split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x2 h = f16x2{(_Float16)v[2 * i], (_Float16)v[2 * i + 1]};
+        const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(v[2 * i]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(v[2 * i + 1]));
+        const f16x2 l = f16x2{(_Float16)r0, (_Float16)r1};
+        hi[2 * i] = h[0]; hi[2 * i + 1] = h[1];
+        lo[2 * i] = l[0]; lo[2 * i + 1] = l[1];
+    }
+}
+
+struct AttnQkvArgs {
+    const float* x;        // (B*T, 128) residual stream entering the layer
+    float* out;            // (B*T, 128) attention output, head h -> columns 32h ..
+    const float* blob[kTencHeads]; // per head: [hi: mt(6)][g(4)][lane] f16x8, [lo] the same, then 384 fp32 (bias in the first 96)
+    int T;
+    int64_t B;
+};
+constexpr int kQkvMT = 6;                                       // M-tiles of a head's projection: Q 0-1, K 2-3, V 4-5
+constexpr int kQkvBlobBytes = 2 * kQkvMT * 4 * 64 * 16 + kStageParams * 4; // 49 152 + 1 536
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void b2h_attn_qkv_h3(AttnQkvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_aq[];
+    constexpr int KS = (NT + 1) / 2;                          // k-steps of 32 keys
+    constexpr int kKBytes = NT * 16 * kTencHd * 2;            // one K image (hi or lo)
+    constexpr int kVBytes = kTencHd * kAttnVtRow * 2;         // one V^T image
+    constexpr int kKV = 2 * kKBytes + 2 * kVBytes;            // K hi, K lo, V^T hi, V^T lo
+    const f32x4* wl = reinterpret_cast<const f32x4*>(smem_aq);
+    const float* prm = reinterpret_cast<const float*>(smem_aq + 2 * kQkvMT * 4 * 64 * 16);
+    char* kvbase = smem_aq + kQkvBlobBytes;
+    // which head, which sequences: blockIdx = 8 * (4 * slot + head) + xcd
+    const int xcd = blockIdx.x & 7, inx = blockIdx.x >> 3, h = inx & 3, slot = inx >> 2;
+    const int nslots = (int)((gridDim.x >> 3) >> 2);          // sequence slots per XCD
+    const int64_t stride = 8 * (int64_t)nslots;
+    int64_t b = (int64_t)slot * 8 + xcd;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
+    const int tq = wave * 16 + col;
+    // the head's weights: once per workgroup
+    for (int i = threadIdx.x; i < kQkvBlobBytes / 16; i += 64 * NT)
+        reinterpret_cast<uint4*>(smem_aq)[i] = reinterpret_cast<const uint4*>(a.blob[h])[i];
+    if (b >= a.B) return; // (after the copy loop only for symmetry; no barrier has been entered yet)
+    auto load_x = [&](f32x4 (&xr)[8], int64_t bb) { // this lane's frame, features 16g + 4q .. +3; rows >= T read 0
+        const bool on = bb < a.B;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.x + (on ? bb : 0) * a.T * kTencD, on ? a.T * kTencD * 4 : 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) xr[g] = chain_ld(rs, (uint32_t)(tq * kTencD + 16 * g + 4 * q) * 4u);
+    };
+    f32x4 xr[8];
+    load_x(xr, b);
+    if (KS * 32 > NT * 16) { // odd NT: the last k-step's upper 16 key slots of V^T have no writer (both buffers)
+        for (int i = threadIdx.x; i < 2 * kTencHd * 16; i += 64 * NT) {
+            const int bufi = i / (kTencHd * 16), r = i % (kTencHd * 16);
+            const int d = r >> 4, p = (KS - 1) * 32 + 8 * ((r >> 2) & 3) + 4 + (r & 3);
+            _Float16* Vh = reinterpret_cast<_Float16*>(kvbase + bufi * kKV + 2 * kKBytes);
+            Vh[d * kAttnVtRow + p] = (_Float16)0.f;
+            (Vh + kTencHd * kAttnVtRow)[d * kAttnVtRow + p] = (_Float16)0.f;
+        }
+    }
+    __syncthreads(); // weights (and the V^T padding) in LDS
+    // key t -> V^T slot: k-step t>>5, then 8*((t>>2)&3) + 4*((t>>4)&1) + (t&3)
+    const int vslot = (tq & ~31) + 8 * ((tq >> 2) & 3) + 4 * ((tq >> 4) & 1) + (tq & 3);
+    int buf = 0;
+#pragma unroll 1
+    for (; b < a.B; b += stride, buf ^= 1) {
+        _Float16* Kh = reinterpret_cast<_Float16*>(kvbase + buf * kKV);
+        _Float16* Kl = Kh + NT * 16 * kTencHd;
+        _Float16* Vh = Kl + NT * 16 * kTencHd;
+        _Float16* Vl = Vh + kTencHd * kAttnVtRow;
+        f16x8 bh[4], bl[4];
+        chain_split(xr, bh, bl);
+        load_x(xr, b + stride); // the next sequence's rows travel under this one's work
+        f32x4 acc[8];
+#pragma unroll
+        for (int mt = 0; mt < kQkvMT; ++mt) acc[mt] = *reinterpret_cast<const f32x4*>(prm + 16 * mt + 4 * q);
+        chain_gemm_h3<4, kQkvMT>(wl, lane, bh, bl, acc);
+        // acc[mt][r] = output 16 mt + 4q + r of this lane's frame: Q_h = outputs 0..31, K_h = 32..63, V_h = 64..95
+        f16x8 qh, ql;
+        {
+            float vq[8], vk[8], vv[8]; // slot (q, j) = dim 16 (j >> 2) + 4q + (j & 3) = accumulator (j >> 2, j & 3)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                vq[j] = acc[j >> 2][j & 3] * 0.17677669529663687f; // torch scales q, not the scores
+                vk[j] = acc[2 + (j >> 2)][j & 3];
+                vv[j] = acc[4 + (j >> 2)][j & 3];
+            }
+            f16x8 kh, kl, vh, vl;
+            tenc_split8(vq, qh, ql);
+            tenc_split8(vk, kh, kl);
+            tenc_split8(vv, vh, vl);
+            *reinterpret_cast<f16x8*>(Kh + tq * kTencHd + 8 * q) = kh;
+            *reinterpret_cast<f16x8*>(Kl + tq * kTencHd + 8 * q) = kl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { // V[key tq][dim 16 (j >> 2) + 4q + (j & 3)] -> V^T[dim][slot of the key]
+                const int d = 16 * (j >> 2) + 4 * q + (j & 3);
+                Vh[d * kAttnVtRow + vslot] = vh[j];
+                Vl[d * kAttnVtRow + vslot] = vl[j];
+            }
+        }
+        __syncthreads(); // K, V of this sequence complete (the other buffer is free again two sequences on)
+        f32x4 sc[2 * KS];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(Kh + (kt * 16 + col) * kTencHd + 8 * q);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(Kl + (kt * 16 + col) * kTencHd + 8 * q);
+            f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qh, s4, 0, 0, 0);
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ql, s4, 0, 0, 0);
+            s4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, qh, s4, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { // D row 4q + r = key index within the tile; only the last tile can cross T
+                if (kt == NT - 1 && kt * 16 + 4 * q + r >= a.T) s4[r] = -INFINITY;
+                mx = fmaxf(mx, s4[r]);
+            }
+            sc[kt] = s4;
+        }
+        if (2 * KS > NT) sc[2 * KS - 1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2 * KS; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[kt][r] = __expf(sc[kt][r] - mx); // v_exp_f32 (1 ulp); masked keys: exp(-inf) = 0
+                l += sc[kt][r];
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            f16x8 ph, pl;
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = sc[2 * s + (j >> 2)][j & 3];
+            tenc_split8(pv, ph, pl);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { // A: V^T row d = 16mt + col, key slots 32s + 8q .. +7
+                const f16x8 vh = *reinterpret_cast<const f16x8*>(Vh + (16 * mt + col) * kAttnVtRow + 32 * s + 8 * q);
+                const f16x8 vl = *reinterpret_cast<const f16x8*>(Vl + (16 * mt + col) * kAttnVtRow + 32 * s + 8 * q);
+                o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[mt], 0, 0, 0);
+                o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[mt], 0, 0, 0);
+                o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[mt], 0, 0, 0);
+            }
+        }
+        const float inv = 1.0f / l;
+        const __amdgpu_buffer_rsrc_t ors = make_rsrc(a.out + b * a.T * kTencD, a.T * kTencD * 4);
+        const int ooff = (tq * kTencD + h * kTencHd + 4 * q) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[0] * inv), ors, ooff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[1] * inv), ors, ooff, 64, 0);
+    }
+}
+
 template <bool H3> // false: fp32 operands (v_mfma_f32_16x16x4_f32); true: 3 x f16 split
 __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a) {
     int nstamp = 0;
