@@ -618,7 +618,8 @@ ChainStage stage_of(const b2h_tenc* m, const TencBlob& B, int type, float* out, 
 
 int launch_chain(b2h_tenc* m, ChainArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * kStageBlobMax * sizeof(float);
-    const int64_t blocks = (a.n + 16 * kLinWaves - 1) / (16 * kLinWaves);
+    // persistent: one workgroup per CU (134 KB of LDS each) walks over the 128-frame blocks
+    const int64_t blocks = std::min<int64_t>((a.n + 16 * kLinWaves - 1) / (16 * kLinWaves), m->num_cus);
     if (m->kernel == B2H_TENC_F16X3)
         hipLaunchKernelGGL(b2h_tenc_chain<true>, dim3((unsigned)blocks), dim3(64 * kLinWaves), lds, st, a);
     else
@@ -772,7 +773,7 @@ int tenc_launch(b2h_tenc* m, const float* x, float* y, int64_t B, int64_t T, con
         const int nt = (int)((T + 15) / 16);
         // persistent: one workgroup per CU, bound to a head (blockIdx = 8 (4 slot + head) + xcd: 32 per sequence slot)
         const unsigned grid = (unsigned)std::max(32, m->num_cus / 32 * 32);
-        const size_t qlds = (size_t)kQkvBlobBytes + 2 * ((size_t)2 * nt * 16 * kTencHd * 2 + (size_t)2 * kTencHd * kAttnVtRow * 2);
+        const size_t qlds = (size_t)kQkvBlobBytes + 2 * ((size_t)2 * nt * 16 * 48 * 2 + (size_t)2 * kTencHd * kAttnVtRow * 2); // K rows of 48 halves
         for (int l = 0; l < m->nlayers; ++l) { // torch.nn.TransformerEncoderLayer, post-norm, ReLU
             auto& L = m->layers[l];
             AttnQkvArgs qa{};

@@ -53,7 +53,7 @@ __device__ unsigned long long g_conv16_span[256 * 8 * 3];
 __device__ unsigned long long g_chain_dbg[8 * 64];
 #define B2H_STAMP()                                                                                        \
     do {                                                                                                   \
-        if (blockIdx.x == gridDim.x / 2 && lane == 0 && a.nstages == 6 && nstamp < 64)                     \
+        if (blockIdx.x == gridDim.x / 2 && lane == 0 && a.nstages == 3 && nstamp < 64)                     \
             g_chain_dbg[wave * 64 + nstamp] = __builtin_amdgcn_s_memtime();                                \
         ++nstamp;                                                                                          \
     } while (0)

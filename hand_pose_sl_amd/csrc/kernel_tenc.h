@@ -446,7 +446,10 @@ template <int NT>
 __global__ __launch_bounds__(64 * NT) void b2h_attn_qkv_h3(AttnQkvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_aq[];
     constexpr int KS = (NT + 1) / 2;                          // k-steps of 32 keys
-    constexpr int kKBytes = NT * 16 * kTencHd * 2;            // one K image (hi or lo)
+    constexpr int kKRow = 48;                                 // halves per K row: 32 dims + 16 of padding -- with 64-B rows
+                                                              // four keys of a ds_read_b128 lane group share a bank quad
+                                                              // (30 % of this kernel's LDS cycles were conflicts); 96 B: none
+    constexpr int kKBytes = NT * 16 * kKRow * 2;              // one K image (hi or lo)
     constexpr int kVBytes = kTencHd * kAttnVtRow * 2;         // one V^T image
     constexpr int kKV = 2 * kKBytes + 2 * kVBytes;            // K hi, K lo, V^T hi, V^T lo
     const f32x4* wl = reinterpret_cast<const f32x4*>(smem_aq);
@@ -488,8 +491,8 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_qkv_h3(AttnQkvArgs a) {
 #pragma unroll 1
     for (; b < a.B; b += stride, buf ^= 1) {
         _Float16* Kh = reinterpret_cast<_Float16*>(kvbase + buf * kKV);
-        _Float16* Kl = Kh + NT * 16 * kTencHd;
-        _Float16* Vh = Kl + NT * 16 * kTencHd;
+        _Float16* Kl = Kh + NT * 16 * kKRow;
+        _Float16* Vh = Kl + NT * 16 * kKRow;
         _Float16* Vl = Vh + kTencHd * kAttnVtRow;
         f16x8 bh[4], bl[4];
         chain_split(xr, bh, bl);
@@ -512,8 +515,8 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_qkv_h3(AttnQkvArgs a) {
             tenc_split8(vq, qh, ql);
             tenc_split8(vk, kh, kl);
             tenc_split8(vv, vh, vl);
-            *reinterpret_cast<f16x8*>(Kh + tq * kTencHd + 8 * q) = kh;
-            *reinterpret_cast<f16x8*>(Kl + tq * kTencHd + 8 * q) = kl;
+            *reinterpret_cast<f16x8*>(Kh + tq * kKRow + 8 * q) = kh;
+            *reinterpret_cast<f16x8*>(Kl + tq * kKRow + 8 * q) = kl;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { // V[key tq][dim 16 (j >> 2) + 4q + (j & 3)] -> V^T[dim][slot of the key]
                 const int d = 16 * (j >> 2) + 4 * q + (j & 3);
@@ -526,8 +529,8 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_qkv_h3(AttnQkvArgs a) {
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(Kh + (kt * 16 + col) * kTencHd + 8 * q);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(Kl + (kt * 16 + col) * kTencHd + 8 * q);
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(Kh + (kt * 16 + col) * kKRow + 8 * q);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(Kl + (kt * 16 + col) * kKRow + 8 * q);
             f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
             s4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, qh, s4, 0, 0, 0);
             s4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ql, s4, 0, 0, 0);
@@ -587,9 +590,12 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, tcol = lane & 15, q = lane >> 4;
     constexpr int kFrames = 16 * kLinWaves, kThreads = 64 * kLinWaves;
-    const int64_t n0 = (int64_t)blockIdx.x * kFrames;               // first frame of the workgroup
-    const int rows = (int)(a.n - n0 < kFrames ? a.n - n0 : kFrames); // frames it owns
-    const int fr = wave * 16 + tcol;                                  // this lane's frame
+    // Persistent since round 3: a workgroup walks over 128-frame blocks (blockIdx.x, + gridDim.x, ...).  With the
+    // Q, K, V stages gone a block is three stages, and the per-workgroup prologue (first blob from L2, row loads
+    // from HBM, the dispatch itself) had grown to a third of a workgroup's life (tools/chain_stamps.py: 15 k of
+    // 46 k cycles); now the next block's first blob travels under this block's last stage.
+    const int nblocks = (int)((a.n + kFrames - 1) / kFrames);         // (< 2^31: the host refuses more)
+    const int fr0 = wave * 16 + tcol;                                 // this lane's frame in its block
     constexpr int kPerThread = (kStageBlobMax / 4 + kThreads - 1) / kThreads; // float4 per thread: 9
     static_assert(kPerThread == 9 && kThreads * 16 == 8192, "blob staging below assumes 9 x 8 KiB");
 
@@ -607,8 +613,17 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
             dst[threadIdx.x + (kPerThread - 1) * kThreads] = w[kPerThread - 1];
     };
 
+    B2H_STAMP(); // 0: entry
     f32x4 wreg[kPerThread];
     fetch_blob(wreg, a.st[0].blob, blob_bytes(0));
+    int gs = 0; // stages done by this workgroup: the parity of the LDS buffer the current stage reads
+#pragma unroll 1
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int64_t n0 = (int64_t)blk * kFrames;                        // first frame of the block
+    const int rows = (int)(a.n - n0 < kFrames ? a.n - n0 : kFrames);  // frames in it
+    const bool next_block = blk + (int)gridDim.x < nblocks;
+    int fr = fr0; // opaque per block: hoisted out of the block loop, the 24 row offsets derived from it stay live
+    asm volatile("" : "+v"(fr)); // through every stage and the kernel spills
     // rows entering the chain (features 16g + 4q .. +3 per k-group), the positional encoding
     // added to them (front launch), and the residual rows of a leading ST_RESLN_GLOBAL stage
     f32x4 cur[8], resid[8];
@@ -647,20 +662,23 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
     }
     f16x8 bh[4], bl[4]; // H3: the GEMM operand, split from `cur`
     if constexpr (H3) chain_split(cur, bh, bl);
-    put_blob(buf0, wreg);
-    B2H_STAMP(); // 0: prologue done
-    __syncthreads();
-    B2H_STAMP(); // 1
+    if (gs == 0) { // the workgroup's first block: its first blob is still in registers
+        put_blob(buf0, wreg);
+        B2H_STAMP(); // 1: prologue done
+        __syncthreads();
+        B2H_STAMP(); // 2: past the first barrier
+    }
 
 #pragma unroll 1
-    for (int s = 0; s < a.nstages; ++s) {
+    for (int s = 0; s < a.nstages; ++s, ++gs) {
         const ChainStage st = a.st[s];
-        f32x4* wl = (s & 1) ? buf1 : buf0;
-        f32x4* wn = (s & 1) ? buf0 : buf1;
+        f32x4* wl = (gs & 1) ? buf1 : buf0;
+        f32x4* wn = (gs & 1) ? buf0 : buf1;
         const float* prm = reinterpret_cast<const float*>(wl + st.wf4);
-        // the next stage's blob is requested now and lands under this stage's MFMAs
+        // the next stage's blob -- after the last stage: the next block's first -- is requested now and lands
+        // under this stage's MFMAs
         const bool more = s + 1 < a.nstages;
-        fetch_blob(wreg, a.st[more ? s + 1 : s].blob, more ? blob_bytes(s + 1) : 0);
+        fetch_blob(wreg, a.st[more ? s + 1 : 0].blob, more ? blob_bytes(s + 1) : (next_block ? blob_bytes(0) : 0));
         // accumulators start from the bias plus the residual (ST_RESLN_GLOBAL, only valid as
         // stage 0, finds the rows read on entry in `resid`)
         const bool addres = st.type == ST_RESLN_GLOBAL || st.type == ST_RESLN_REG;
@@ -772,6 +790,7 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
         if (!(B2H_ABLATE & 2048)) __syncthreads();
         B2H_STAMP(); // 7 + 6s: past the barrier
     }
+    } // blocks
 }
 
 } // namespace b2h
