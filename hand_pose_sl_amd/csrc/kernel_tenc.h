@@ -588,7 +588,7 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
     f32x4* buf0 = reinterpret_cast<f32x4*>(smem_chain);
     f32x4* buf1 = buf0 + kStageBlobMax / 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, tcol = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63, tcol = lane & 15, q0 = lane >> 4;
     constexpr int kFrames = 16 * kLinWaves, kThreads = 64 * kLinWaves;
     // Persistent since round 3: a workgroup walks over 128-frame blocks (blockIdx.x, + gridDim.x, ...).  With the
     // Q, K, V stages gone a block is three stages, and the per-workgroup prologue (first blob from L2, row loads
@@ -622,8 +622,9 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
     const int64_t n0 = (int64_t)blk * kFrames;                        // first frame of the block
     const int rows = (int)(a.n - n0 < kFrames ? a.n - n0 : kFrames);  // frames in it
     const bool next_block = blk + (int)gridDim.x < nblocks;
-    int fr = fr0; // opaque per block: hoisted out of the block loop, the 24 row offsets derived from it stay live
-    asm volatile("" : "+v"(fr)); // through every stage and the kernel spills
+    int fr = fr0, q = q0; // opaque per block: hoisted out of the block loop, the 24 row offsets derived from `fr`
+    asm volatile("" : "+v"(fr), "+v"(q)); // and the eight `have` masks (16 SGPRs) and feature offsets derived from
+    // `q` stay live through every stage, and the kernel spills vector and scalar registers
     // rows entering the chain (features 16g + 4q .. +3 per k-group), the positional encoding
     // added to them (front launch), and the residual rows of a leading ST_RESLN_GLOBAL stage
     f32x4 cur[8], resid[8];
@@ -633,6 +634,9 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
         const __amdgpu_buffer_rsrc_t rrs = make_rsrc(a.res ? a.res + n0 * kTencD : nullptr, a.res ? rows * kTencD * 4 : 0);
         const uint32_t pos = (uint32_t)((n0 + fr) % (a.T > 0 ? a.T : 1));
         const int pre = __builtin_amdgcn_readfirstlane(a.flags) & (kPreChest | kPreNorm);
+        // one bound for "k-group exists and feature is valid" (4q < 16, so g < kgroups0 <=> 16g + 4q < 16 kgroups0);
+        // as two tests per k-group the compiler kept eight lane masks in 16 SGPRs across the block loop and spilled
+        const int klim = 16 * a.kgroups0 < a.kvalid ? 16 * a.kgroups0 : a.kvalid;
         f32x4 chest = {0.f, 0.f, 0.f, 0.f};
         if (pre & kPreChest) { // joint 1 = channels 2, 3 of the frame's own row: (x, y, x, y) per float4
             const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)((uint32_t)(fr * a.ldx + 2) * 4u), 0, 0);
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int k0 = 16 * g + 4 * q;
-            const bool have = g < a.kgroups0 && k0 < a.kvalid;
+            const bool have = k0 < klim; // g < kgroups0 && k0 < kvalid
             cur[g] = chain_ld(xrs, have ? (uint32_t)(fr * a.ldx + k0) * 4u : kOob);
             if (pre) { // wave-uniform; lanes without data hold zeros and stay zero
                 if (have) cur[g] -= chest;

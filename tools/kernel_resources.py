@@ -28,10 +28,10 @@ def demangle(n):
         return subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip().split("(")[0]
     except OSError:
         return n
-print(f"{'kernel':58s} {'VGPR':>5s} {'AGPR':>5s} {'SGPR':>5s} {'scratch':>8s} {'spill':>6s} {'occ':>4s} {'LDS':>7s}")
+print(f"{'kernel':58s} {'VGPR':>5s} {'AGPR':>5s} {'SGPR':>5s} {'scratch':>8s} {'vspill':>6s} {'sspill':>6s} {'occ':>4s} {'LDS':>7s}")
 for r_ in rows:
     n = demangle(r_["name"])
     if flt and flt not in n:
         continue
     print(f"{n[-58:]:58s} {r_.get('VGPRs','?'):>5s} {r_.get('AGPRs','?'):>5s} {r_.get('TotalSGPRs','?'):>5s} {r_.get('ScratchSize [bytes/lane]','?'):>8s} "
-          f"{r_.get('VGPRs Spill','?'):>6s} {r_.get('Occupancy [waves/SIMD]','?'):>4s} {r_.get('LDS Size [bytes/block]','?'):>7s}")
+          f"{r_.get('VGPRs Spill','?'):>6s} {r_.get('SGPRs Spill','?'):>6s} {r_.get('Occupancy [waves/SIMD]','?'):>4s} {r_.get('LDS Size [bytes/block]','?'):>7s}")
