@@ -24,6 +24,7 @@
 // On gfx950 MFMA and VALU work do not overlap on a SIMD (tools/mfma_bench.hip), so there is
 // no attempt to hide epilogues under MFMAs: the bound is their sum.
 #pragma once
+#include <utility>
 #include "b2h_common.h"
 #include "kernel_mfma.h"   // f32x4
 #include "kernel_mfma16.h" // pack helpers
@@ -38,6 +39,25 @@ constexpr int kTencHeads = 4;
 constexpr int kTencHd = 32;      // head dim
 constexpr int kLinWaves = 8;     // waves per workgroup of the linear kernel (16 frames each)
 constexpr int kLinChunkMT = 8;   // M-tiles (x16 features) of weights staged in LDS at a time
+
+// Sum / max over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} that hold one frame's values, left in all four.
+// Two __shfl_xor = ds_bpermute_b32 + s_waitcnt lgkmcnt(0) each.  Round 3 tried v_permlane16_swap /
+// v_permlane32_swap (gfx950) on two copies of the value instead (swap(a, b) exchanges a's odd rows or upper half
+// with b's even rows or lower half, so a + b is the pairwise sum in every lane): correct as inline asm with the
+// two wait states the swap needs after a vector write of its operands (tools/permlane_probe.hip; the BUILTINS of
+// this hipcc return the first result twice: 0 of 64 lanes right), but 0.8 % SLOWER on the f16x3 forward in a
+// same-process A/B (profiles/r3_tenc/ab_gemm_units_and_permlane.txt): the shuffle's latency was already hidden
+// by the SIMD's other wave, the swaps' nops and issue slots are not.
+__device__ __forceinline__ float quad_sum(float s) {
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s;
+}
+__device__ __forceinline__ float quad_max(float s) {
+    s = fmaxf(s, __shfl_xor(s, 16, 64));
+    s = fmaxf(s, __shfl_xor(s, 32, 64));
+    return s;
+}
 
 // Self-attention on the matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32): softmax(q k^T) v with
 // q pre-scaled by head_dim^-0.5 (torch.nn.MultiheadAttention).
@@ -109,8 +129,7 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_f32(const float* __rest
             mx = fmaxf(mx, sc[kt][r]);
         }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = quad_max(mx);
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
@@ -119,8 +138,7 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_f32(const float* __rest
             sc[kt][r] = expf(sc[kt][r] - mx); // masked keys: exp(-inf) = 0
             l += sc[kt][r];
         }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = quad_sum(l);
     // O^T[d][query]: for step (kt, r) lane q supplies P^T[kt*16 + 4q + r][query] = sc[kt][r];
     // the A operand is V[kt*16 + 4q + r][16mt + col]
     f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -238,8 +256,7 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_h3(const float* __restr
         sc[kt] = a;
     }
     if (2 * KS > NT) sc[2 * KS - 1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = quad_max(mx);
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2 * KS; ++kt)
@@ -248,8 +265,7 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_mfma_h3(const float* __restr
             sc[kt][r] = __expf(sc[kt][r] - mx); // v_exp_f32 (1 ulp); masked keys: exp(-inf) = 0
             l += sc[kt][r];
         }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = quad_sum(l);
     f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -365,7 +381,7 @@ __device__ __forceinline__ void chain_split(const f32x4 (&v)[8], f16x8 (&bh)[4],
         }
 }
 
-template <int KG, int MT> // blob: [hi: mt][g][lane] f16x8, then [lo] the same
+template <int KG, int MT>
 __device__ __forceinline__ void chain_gemm_h3(const f32x4* __restrict__ wl, int lane, const f16x8 (&bh)[4],
                                               const f16x8 (&bl)[4], f32x4 (&acc)[8]) {
     const f16x8* whi = reinterpret_cast<const f16x8*>(wl);
@@ -385,6 +401,61 @@ __device__ __forceinline__ void chain_gemm_h3(const f32x4* __restrict__ wl, int 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[g], acc[mt], 0, 0, 0);
     }
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int KG, int MT, int UM = (MT + 1) / 2, int D = 1>
+__device__ __forceinline__ void chain_gemm_h3_db(const f32x4* __restrict__ wl, int lane, const f16x8 (&bh)[4],
+                                                 const f16x8 (&bl)[4], f32x4 (&acc)[8]) {
+    // Round 3: the fragments travel in UNITS of UM M-tiles of one k-group (UM hi + UM lo fragments), through a
+    // ring of D + 1 unit buffers: unit u + D is requested from LDS before unit u's MFMAs are issued, so its
+    // ~200 cycles of LDS latency lie under MFMAs instead of in front of them.  Before, a whole k-group (16
+    // fragments) was requested and then waited for, four times per GEMM: stamps showed 3.3-3.5 k cycles per
+    // 96 MFMAs even with half the workgroup's waves idle (tools/chain_stamps.py), against ~1.6 k of issue time.
+    // Per accumulator the products are added in the same order as before (k-group by k-group: lo.hi, hi.lo,
+    // hi.hi).
+    constexpr int NU = (MT + UM - 1) / UM; // units per k-group
+    constexpr int U = NU * KG;
+    const f16x8* whi = reinterpret_cast<const f16x8*>(wl) + lane;
+    const f16x8* wlo = whi + MT * KG * 64;
+    f16x8 ah[D + 1][UM], al[D + 1][UM];
+    auto load = [&](auto uc) {
+        constexpr int u = decltype(uc)::value, g = u / NU, m0 = (u % NU) * UM, n = (MT - m0 < UM) ? MT - m0 : UM;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            ah[u % (D + 1)][i] = whi[((m0 + i) * KG + g) * 64];
+            al[u % (D + 1)][i] = wlo[((m0 + i) * KG + g) * 64];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * n, 0); // pin the order: these reads ...
+    };
+    auto mma = [&](auto uc) {
+        constexpr int u = decltype(uc)::value, g = u / NU, m0 = (u % NU) * UM, n = (MT - m0 < UM) ? MT - m0 : UM;
+        const f16x8 (&h)[UM] = ah[u % (D + 1)];
+        const f16x8 (&l)[UM] = al[u % (D + 1)];
+#pragma unroll
+        for (int i = 0; i < n; ++i) acc[m0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(l[i], bh[g], acc[m0 + i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < n; ++i) acc[m0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[i], bl[g], acc[m0 + i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < n; ++i) acc[m0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[i], bh[g], acc[m0 + i], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * n, 0); // ... then these MFMAs
+    };
+    auto pre = [&](auto uc) { if constexpr (decltype(uc)::value < U) load(uc); };
+    static_for<D>(pre);
+    auto step = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (u + D < U) load(std::integral_constant<int, u + D>{});
+        mma(uc);
+    };
+    static_for<U>(step);
 }
 
 // Memory operations are buffer instructions over per-workgroup descriptors: the hardware range
@@ -543,8 +614,7 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_qkv_h3(AttnQkvArgs a) {
             sc[kt] = s4;
         }
         if (2 * KS > NT) sc[2 * KS - 1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = quad_max(mx);
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2 * KS; ++kt)
@@ -553,8 +623,7 @@ __global__ __launch_bounds__(64 * NT) void b2h_attn_qkv_h3(AttnQkvArgs a) {
                 sc[kt][r] = __expf(sc[kt][r] - mx); // v_exp_f32 (1 ulp); masked keys: exp(-inf) = 0
                 l += sc[kt][r];
             }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = quad_sum(l);
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -695,9 +764,9 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
         B2H_STAMP(); // 2 + 6s: fetch issued, accumulators initialised
         // the GEMM, branch-free for the three shapes the model has
         if constexpr (H3) {
-            if (st.kgroups == 4 && st.mtiles == 8) chain_gemm_h3<4, 8>(wl, lane, bh, bl, acc);
-            else if (st.kgroups == 1) chain_gemm_h3<1, 8>(wl, lane, bh, bl, acc);
-            else chain_gemm_h3<4, 3>(wl, lane, bh, bl, acc);
+            if (st.kgroups == 4 && st.mtiles == 8) chain_gemm_h3_db<4, 8>(wl, lane, bh, bl, acc);
+            else if (st.kgroups == 1) chain_gemm_h3_db<1, 8>(wl, lane, bh, bl, acc);
+            else chain_gemm_h3_db<4, 3>(wl, lane, bh, bl, acc);
         } else {
             if (st.kgroups == 8 && st.mtiles == 8) chain_gemm<8, 8>(wl, lane, cur, acc);
             else if (st.kgroups == 2) chain_gemm<2, 8>(wl, lane, cur, acc);
@@ -713,8 +782,7 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
             float sum = 0.f;
 #pragma unroll
             for (int m = 0; m < 8; ++m) sum += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = quad_sum(sum);
             const float mean = sum * (1.0f / kTencD);
             float var = 0.f;
 #pragma unroll
@@ -724,8 +792,7 @@ __global__ __launch_bounds__(64 * kLinWaves, 2) void b2h_tenc_chain(ChainArgs a)
                     const float d = acc[m][r] - mean;
                     var += d * d;
                 }
-            var += __shfl_xor(var, 16, 64);
-            var += __shfl_xor(var, 32, 64);
+            var = quad_sum(var);
             const float rstd = 1.0f / sqrtf(var * (1.0f / kTencD) + 1e-5f);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
