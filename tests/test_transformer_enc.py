@@ -75,6 +75,28 @@ def test_hip_matches_reference(name, precision, cuda_device):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", PRECISIONS)
+def test_hip_lengths_up_to_128_with_a_longer_positional_table(precision, cuda_device):
+    """The C ABI takes max_len up to 128 (b2h_tenc_create); the reference's class hard-codes 100
+    (HandPoseModels.py:129) but its PositionalEncoding is a plain module a user can swap.  Lengths 101 ... 128
+    run the eight-tile attention instantiations (b2h_attn_qkv_h3<8> / b2h_attn_mfma_*<8>), which no other test
+    reaches: seven full tiles + a partial one, exactly eight, and the tile edges around them."""
+    m, state, _ = _gpu_model(cuda_device, precision)
+    m.pos_encoder = hps.PositionalEncoding(24, 0.5, max_len=128).to(cuda_device)
+    state = dict(state)
+    state["pos_encoder.pe"] = m.pos_encoder.pe.cpu().numpy()
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for T in (100, 101, 111, 112, 113, 127, 128):
+            x = torch.rand((5, T, 12, 2), generator=g) - 0.5
+            y = m(x.to(cuda_device))
+            ref = oracle.transformer_forward(x.numpy(), state)
+            assert np.abs(y.cpu().numpy() - ref).max() <= TOL, T
+        with pytest.raises(RuntimeError, match="max_len"):
+            m(torch.zeros((1, 129, 12, 2)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_hip_batch_independence_lengths_and_errors(precision, cuda_device):
     m, state, _ = _gpu_model(cuda_device, precision)
     g = torch.Generator().manual_seed(7)
