@@ -385,8 +385,10 @@ int set_conv_kernel_attributes() {
         (rc = raise_lds_cap(b2h_fwd_mfma_f32<false, true>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f32<true, true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma_f16x3<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3<true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma_f16x3w<false>)) || (rc = raise_lds_cap(b2h_fwd_mfma_f16x3w<true>)) ||
-        (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, true>)) ||
-        (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, true>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, false, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, true, false>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, false, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, true, false>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, false, true>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_BF16, true, true>)) ||
+        (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, false, true>)) || (rc = raise_lds_cap(b2h_fwd_mfma16<PREC_F16, true, true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_BF16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_BF16, true>)) ||
         (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_F16, false>)) || (rc = raise_lds_cap(b2h_fwd_mfma16w<PREC_F16, true>)))
         return rc;
@@ -522,13 +524,17 @@ int launch(b2h_model* m, const float* x, float* y, int64_t B, int64_t T, int ker
             const bool fused = fa.flags != 0;
             const bool bf = (k == B2H_KERNEL_BF16_MFMA);
             const void* wp = bf ? m->mbf16_all.p : m->mf16_all.p;
-#define B2H_LAUNCH16(PR, FU)                                                                          \
-    hipLaunchKernelGGL((b2h_fwd_mfma16<PR, FU>), dim3(grid16), dim3(64 * kWaves16), kLdsAlloc16, st, x, y, \
+            // streaming cache policy (kernel_mfma.h: kLdStream / kStStream) from 1 MiB of traffic up
+            const bool stream = B * T * (int64_t)((kInCh + kOutCh) * 4) >= (1 << 20);
+#define B2H_LAUNCH16(PR, FU, SM)                                                                          \
+    hipLaunchKernelGGL((b2h_fwd_mfma16<PR, FU, SM>), dim3(grid16), dim3(64 * kWaves16), kLdsAlloc16, st, x, y, \
                        (int)T, cps16, TT, nch, wp, m->pos_emb, fa, sched)
-            if (bf && !fused) B2H_LAUNCH16(PREC_BF16, false);
-            else if (bf) B2H_LAUNCH16(PREC_BF16, true);
-            else if (!fused) B2H_LAUNCH16(PREC_F16, false);
-            else B2H_LAUNCH16(PREC_F16, true);
+#define B2H_LAUNCH16S(PR, FU) do { if (stream) B2H_LAUNCH16(PR, FU, true); else B2H_LAUNCH16(PR, FU, false); } while (0)
+            if (bf && !fused) B2H_LAUNCH16S(PREC_BF16, false);
+            else if (bf) B2H_LAUNCH16S(PREC_BF16, true);
+            else if (!fused) B2H_LAUNCH16S(PREC_F16, false);
+            else B2H_LAUNCH16S(PREC_F16, true);
+#undef B2H_LAUNCH16S
 #undef B2H_LAUNCH16
         }
 #undef B2H_LAUNCHC
@@ -1041,8 +1047,8 @@ const char* b2h_kernel_name(const b2h_model* m, int kernel) {
     switch (resolve_kernel(m, kernel)) {
         case B2H_KERNEL_F32_VALU: return "b2h_fwd_f32_valu";
         case B2H_KERNEL_F32_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma_f32<false, true>" : "b2h_fwd_mfma_f32<false, false>";
-        case B2H_KERNEL_BF16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<1, false>" : "b2h_fwd_mfma16<1, false>";
-        case B2H_KERNEL_F16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<2, false>" : "b2h_fwd_mfma16<2, false>";
+        case B2H_KERNEL_BF16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<1, false>" : "b2h_fwd_mfma16<1, false, true>";
+        case B2H_KERNEL_F16_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma16w<2, false>" : "b2h_fwd_mfma16<2, false, true>";
         case B2H_KERNEL_F16X3_MFMA: return m->C > kMfmaWidth ? "b2h_fwd_mfma_f16x3w<false>" : "b2h_fwd_mfma_f16x3<false>";
         default: return "";
     }

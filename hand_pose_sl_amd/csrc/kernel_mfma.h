@@ -82,6 +82,17 @@ struct ChunkCtx {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// Cache policy of the streams (the aux operand of the buffer builtins: 1 = sc0, 2 = nt, 16 = sc1).  The rows a
+// kernel reads and the rows it writes are touched once per launch and are far larger than L2 + Infinity Cache,
+// so they are marked non-temporal, and stores additionally get device scope (sc1), which sends them through to
+// memory instead of leaving dirty lines for L2 to evict later in its own order.  Round 3, same-process A/B with
+// ONE output buffer (profiles/r3_bf16/ab_cache_policy.txt), bf16 kernel at 262 144 x 200: default 2 725 us,
+// nt stores 2 687, nt loads alone 2 726, nt both 2 672, nt loads + nt sc1 stores 2 663 (-2.3 %); at
+// 2 000 x 200 26.6 -> 23.4 us (no write-back of dirty lines left for the end of the kernel).  Weights,
+// biases and positional tables keep the default policy: they are what L2 is for.
+constexpr int kLdStream = 2;
+constexpr int kStStream = 18;
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, bytes, 0x00020000);
 }
@@ -90,6 +101,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, in
 // frame t: 16 B at byte 168 (t - s) + 64 mt + 16 q of the chunk's output rows [s, e), stored with
 // buffer_store_dwordx4 (rows are 8-byte aligned only, which buffer stores allow); frames >= e fall
 // outside the descriptor and are dropped by the range check, channels 40, 41 are an 8-byte store.
+// Default cache policy on purpose: these are 64-byte pieces of 128-byte lines that L2 has to merge -- with the
+// streaming policy of the lane-linear stores (kStStream) the f16x3 kernel ran 1 548 -> 2 923 us.
 // Every offset that varies is in the VGPR offset (immediate soffset), so hipcc pads the store-data
 // write-after-read hazard itself (tests/test_isa_audit.py).
 // FUSED: x factor (traintest.py:387-388) and the tail mask (utils.py:309-312); the plain
@@ -180,7 +193,7 @@ __device__ __forceinline__ StagedRows stage_rows(const ChunkCtx& cx, const float
     float4 v[kStageRegs];
 #pragma unroll
     for (int u = 0; u < kStageRegs; ++u)
-        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, cx.lane * 16, u * 1024, 0));
+        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, cx.lane * 16, u * 1024, kLdStream));
     int rr[3], off[3];
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {

@@ -88,11 +88,14 @@ struct InRegs16 { uint2 p[kInRegs]; };  // the same, cast to 4 x 16-bit
 
 // Request a chunk's input rows: 20 x 16 B per lane, lane-contiguous (coalesced 1 KiB
 // per instruction).  bytes == 0 (nothing left to prefetch) issues no memory traffic.
+// AUX: cache policy (kLdStream for a streaming launch; 0 when the rows are read again: the fused
+// chest difference re-reads two floats of every row, and tiny launches gain nothing from it).
+template <int AUX>
 __device__ __forceinline__ void issue_loads16(InRegs& R, const float* base, int bytes, int lane) {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, bytes);
 #pragma unroll
     for (int j = 0; j < kInRegs; ++j) {
-        const i32x4 r = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0));
+        const i32x4 r = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, AUX));
         R.v[j] = __builtin_bit_cast(float4, r);
     }
 }
@@ -208,7 +211,7 @@ __device__ __forceinline__ void commit16(const InRegs16& Q, char* lds, const Geo
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int PREC, int L, bool FUSED>
+template <int PREC, int L, bool FUSED, bool STREAM>
 __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom16& g, int T,
                                          int lane, float* __restrict__ yseq, float mul, int nvalid) {
     using P = Prec<PREC>;
@@ -324,9 +327,9 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
             u32x4 o[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) o[i] = *(lds_u32x4*)(strd + 1024 * i);
-            __builtin_amdgcn_raw_buffer_store_b128(o[0], yrs, yoff, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(o[1], yrs, yoff, so + 1024, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(o[2], yrs, yoff2, so + 2048, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o[0], yrs, yoff, so, STREAM ? kStStream : 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o[1], yrs, yoff, so + 1024, STREAM ? kStStream : 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o[2], yrs, yoff2, so + 2048, STREAM ? kStStream : 0);
         }
     };
     // F: the five fragments of the tile k tiles ahead.  Unconditional: past the last tile it reads
@@ -390,7 +393,11 @@ struct Sched16 {
     unsigned kstatic;
 };
 
-template <int PREC, bool FUSED>
+// STREAM: the launch is a stream (its rows are touched once and exceed the caches): non-temporal input loads
+// (unless FUSED) and non-temporal device-scope output stores, see kLdStream / kStStream in kernel_mfma.h.  The
+// host picks it for launches of >= 1 MiB of traffic; a single short sequence is 0.9 us FASTER with the default
+// policy (its few stores complete in L2 instead of in memory before the kernel can end).
+template <int PREC, bool FUSED, bool STREAM>
 __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     const float* __restrict__ x, float* __restrict__ y, int T, int cps, int TT, int64_t nchunks,
     const void* __restrict__ wpacked, int pos_emb, FusedArgs fa, Sched16 sched) {
@@ -439,7 +446,8 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     InRegs R;
     InRegs16 Q;
     Geom16 g = geom16(chunk, cps, TT, T);
-    issue_loads16(R, src_of(g), g.nf4 * 16, lane);
+    constexpr int kLd = (STREAM && !FUSED) ? kLdStream : 0;
+    issue_loads16<kLd>(R, src_of(g), g.nf4 * 16, lane);
     convert16<PREC, FUSED>(R, Q, src_of(g), g.nf4, lane, fu);
     while (true) {
         B2H_STAMP16(wave, lane, it, 0);
@@ -463,15 +471,15 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
         const Geom16 gn = more ? geom16(next, cps, TT, T) : g;
         const int nf4n = more ? gn.nf4 : 0;
         B2H_STAMP16(wave, lane, it, 1);
-        issue_loads16(R, src_of(gn), nf4n * 16, lane); // flies under layers 1-2
+        issue_loads16<kLd>(R, src_of(gn), nf4n * 16, lane); // flies under layers 1-2
         float* yseq = y + g.seq * (int64_t)T * kOutCh;
         int nvalid = T;
         if constexpr (FUSED)
             if (fu.mask) nvalid = (int)min((int64_t)T, max((int64_t)0, fa.n_frames[g.seq]));
         B2H_STAMP16(wave, lane, it, 2);
-        layer16p<PREC, 0, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
+        layer16p<PREC, 0, FUSED, STREAM>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
         B2H_STAMP16(wave, lane, it, 3);
-        layer16p<PREC, 1, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
+        layer16p<PREC, 1, FUSED, STREAM>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
         B2H_STAMP16(wave, lane, it, 4);
         // The prefetch has had two layers to land.  Wait for it HERE -- the only vector-memory
         // operations still in flight are those loads (with the pool claim before them) and the previous
@@ -485,9 +493,9 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
         B2H_STAMP16(wave, lane, it, 5);
         convert16<PREC, FUSED>(R, Q, src_of(gn), nf4n, lane, fu);
         pin_regs16(Q);
-        layer16p<PREC, 2, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
+        layer16p<PREC, 2, FUSED, STREAM>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
         B2H_STAMP16(wave, lane, it, 6);
-        layer16p<PREC, 3, FUSED>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
+        layer16p<PREC, 3, FUSED, STREAM>(lds, smem16, g, T, lane, yseq, fu.mul, nvalid);
         B2H_STAMP16(wave, lane, it, 7);
         if (!more) break; // claims only grow: next2 is past the end as well
         chunk = next;

@@ -197,7 +197,9 @@ int b2h_model_info(const b2h_model* m, int* conv_channels, int* pos_emb, int* ha
 /* 1 if `kernel` can run this model (width, pos_emb), else 0. */
 int b2h_kernel_supported(const b2h_model* m, int kernel);
 /* Name of the __global__ function `kernel` resolves to for this model (for
- * matching rocprofv3 kernel-trace rows); static storage. */
+ * matching rocprofv3 kernel-trace rows); static storage.  The plain (unfused) instantiation; for the
+ * persistent 16-bit kernel the streaming one, b2h_fwd_mfma16<PREC, false, true>, which every launch of
+ * >= 1 MiB of traffic runs (smaller launches run its <PREC, false, false> twin: default cache policy). */
 const char* b2h_kernel_name(const b2h_model* m, int kernel);
 /* Time `iters` back-to-back launches of b2h_forward on `stream` with HIP events
  * recorded on that stream; returns the average milliseconds per launch. */

@@ -29,21 +29,31 @@ for p in paths:
     h = ctypes.c_void_p()
     assert lib.b2h_create(30, b"ReLU", 0, ctypes.byref(h)) == 0
     assert lib.b2h_load_weights(h, *[ctypes.c_void_p(t.data_ptr()) for t in ps], 1) == 0
-    y = torch.empty((S, T, 21, 2), device=dev)
-    libs.append((lib, h, y))
+    libs.append((lib, h, None))
 k = _lib.KERNELS[prec]
 def t(lib, h, y, iters):
     ms = ctypes.c_float()
     rc = lib.b2h_time_forward(h, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), S, T, k, iters, None, ctypes.byref(ms))
     assert rc == 0, lib.b2h_last_error()
     return ms.value
-for lib, h, y in libs:
+# ONE output buffer for every library: where a buffer lies in HBM moves the time by ~1 % (the same library at
+# three positions of this list, each with its own buffer: 2 793 / 2 793 / 2 766 us), which is the size of the
+# effects this tool is used to find.  Identity is checked against a copy of the first library's output.
+y = torch.empty((S, T, 21, 2), device=dev)
+same = []
+ref = None
+for lib, h, _ in libs:
     t(lib, h, y, 20)
+    if ref is None:
+        ref = y.clone()
+    else:
+        same.append(bool(torch.equal(ref, y)))
+del ref
 res = [[] for _ in libs]
 for r in range(12):
-    for i, (lib, h, y) in enumerate(libs):
+    for i, (lib, h, _) in enumerate(libs):
         res[i].append(t(lib, h, y, 40))
 torch.cuda.synchronize()
-print("outputs identical to the first:", [bool(torch.equal(libs[0][2], l[2])) for l in libs[1:]])
+print("outputs identical to the first:", same)
 for i, p in enumerate(paths):
     print(f"{p}: median {statistics.median(res[i])*1e3:.1f} us  min {min(res[i])*1e3:.1f} us  ({S*T/statistics.median(res[i])/1e6:.2f} G frames/s)")
