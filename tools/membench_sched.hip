@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int T = 200, XB = T * 96, YB = T * 168;
@@ -27,7 +28,7 @@ __device__ __forceinline__ unsigned long long rt() { return __builtin_amdgcn_s_m
 // GROUPS = 1: all 33 stores back to back.  GROUPS = 13: 13 groups (3,3,...,3 -> 39 slots, 33 real)
 // with s_sleep(SLEEP) between them.  PREFETCH: the next sequence's loads are issued before this
 // sequence's stores (the kernel's order).
-template <int GROUPS, int SLEEP, bool PREFETCH>
+template <int GROUPS, int SLEEP, bool PREFETCH, int LA = 0, int SA = 0> // LA / SA: cache policy (aux) of loads / stores
 __global__ void k_trickle(const char* __restrict__ x, char* __restrict__ y, int nseq, unsigned* sink) {
     const int W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -39,7 +40,7 @@ __global__ void k_trickle(const char* __restrict__ x, char* __restrict__ y, int 
     {
         const __amdgpu_buffer_rsrc_t rs = rsrc(x + (size_t)seq * XB, XB);
 #pragma unroll
-        for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0);
+        for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, LA);
     }
     for (; seq < nseq; seq += stride) {
 #pragma unroll
@@ -48,7 +49,7 @@ __global__ void k_trickle(const char* __restrict__ x, char* __restrict__ y, int 
             const int nx = seq + stride;
             const __amdgpu_buffer_rsrc_t rs = rsrc(x + (size_t)(nx < nseq ? nx : seq) * XB, nx < nseq ? XB : 0);
 #pragma unroll
-            for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0);
+            for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, LA);
         }
         const __amdgpu_buffer_rsrc_t ws = rsrc(y + (size_t)seq * YB, YB);
         const u32x4 d = {acc, 2u, 3u, (unsigned)seq};
@@ -57,21 +58,21 @@ __global__ void k_trickle(const char* __restrict__ x, char* __restrict__ y, int 
         for (int g = 0; g < GROUPS; ++g) {
 #pragma unroll
             for (int j = g * PER; j < (g + 1) * PER && j < 33; ++j)
-                __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, SA);
             if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
         }
         if (!PREFETCH) {
             const int nx = seq + stride;
             const __amdgpu_buffer_rsrc_t rs = rsrc(x + (size_t)(nx < nseq ? nx : seq) * XB, nx < nseq ? XB : 0);
 #pragma unroll
-            for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0);
+            for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, LA);
         }
     }
     if (acc == 0x12345679u) sink[0] = acc;
 }
 
 // ---- half sequences (100 frames + 8 halo: 108 rows in = 11 loads, 100 rows out = 17 stores) -----
-template <int GROUPS, int SLEEP>
+template <int GROUPS, int SLEEP, int LA = 0, int SA = 0>
 __global__ void k_half(const char* __restrict__ x, char* __restrict__ y, int nseq, unsigned* sink) {
     const int W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -84,7 +85,7 @@ __global__ void k_half(const char* __restrict__ x, char* __restrict__ y, int nse
         const int s = c >> 1, h = c & 1;
         const __amdgpu_buffer_rsrc_t rs = rsrc(x + (size_t)s * XB + (h ? 92 * 96 : 0), on ? 108 * 96 : 0);
 #pragma unroll
-        for (int j = 0; j < 11; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0);
+        for (int j = 0; j < 11; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, LA);
     };
     issue(ch, true);
     for (; ch < nch; ch += stride) {
@@ -100,7 +101,7 @@ __global__ void k_half(const char* __restrict__ x, char* __restrict__ y, int nse
         for (int g = 0; g < GROUPS; ++g) {
 #pragma unroll
             for (int j = g * PER; j < (g + 1) * PER && j < 17; ++j)
-                __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, SA);
             if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
         }
     }
@@ -212,6 +213,27 @@ int main(int argc, char** argv) {
         fflush(stdout);
     };
 #define L(K, W) [&] { hipLaunchKernelGGL(K, dim3(256), dim3(64 * (W)), 0, 0, x, y, nseq, sink); }
+    if (argc > 2 && !strcmp(argv[2], "policy")) { // cache policies (aux: 1 = sc0, 2 = nt, 16 = sc1) on the kernel's pattern
+        for (int rep = 0; rep < 2; ++rep) {
+            printf("# policy pass %d, %d sequences\n", rep, nseq);
+            run("base W=8 prefetch, loads 0  stores 0", bytes, L((k_trickle<1, 0, true, 0, 0>), 8));
+            run("base W=8 prefetch, loads 0  stores nt", bytes, L((k_trickle<1, 0, true, 0, 2>), 8));
+            run("base W=8 prefetch, loads nt stores nt", bytes, L((k_trickle<1, 0, true, 2, 2>), 8));
+            run("base W=8 prefetch, loads nt stores nt sc1", bytes, L((k_trickle<1, 0, true, 2, 18>), 8));
+            run("base W=8 prefetch, loads 0  stores nt sc1", bytes, L((k_trickle<1, 0, true, 0, 18>), 8));
+            run("base W=8 prefetch, loads 0  stores sc1", bytes, L((k_trickle<1, 0, true, 0, 16>), 8));
+            run("base W=8 prefetch, loads 0  stores sc0 sc1", bytes, L((k_trickle<1, 0, true, 0, 17>), 8));
+            run("base W=8 prefetch, loads nt sc1 stores nt sc1", bytes, L((k_trickle<1, 0, true, 18, 18>), 8));
+            run("trickle W=8 11 x 3 sleep 10, loads nt stores nt sc1", bytes, L((k_trickle<11, 10, true, 2, 18>), 8));
+            run("trickle W=8 11 x 3 sleep 10, loads 0 stores 0", bytes, L((k_trickle<11, 10, true, 0, 0>), 8));
+            run("half W=12, loads 0 stores 0", bytes, L((k_half<1, 0, 0, 0>), 12));
+            run("half W=12, loads nt stores nt sc1", bytes, L((k_half<1, 0, 2, 18>), 12));
+            run("half W=12 6 x 3 sleep 10, loads nt stores nt sc1", bytes, L((k_half<6, 10, 2, 18>), 12));
+            run("base W=4 prefetch, loads nt stores nt sc1", bytes, L((k_trickle<1, 0, true, 2, 18>), 4));
+            run("base W=16 prefetch, loads nt stores nt sc1", bytes, L((k_trickle<1, 0, true, 2, 18>), 16));
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) { // twice: box drift shows as a difference between the two passes
         printf("# pass %d, %d sequences\n", rep, nseq);
         run("base W=8 (19 loads, 33 stores, no prefetch)", bytes, L((k_trickle<1, 0, false>), 8));
