@@ -383,14 +383,16 @@ __device__ __forceinline__ void layer16p(char* lds, const char* wlds, const Geom
     }
 }
 
-// Work distribution of one launch (filled by the host, b2h_api.hip).  Workgroup b (of G) owns the STATIC
-// chunks b + G k, k < kstatic; the chunks [G kstatic, nchunks) form a POOL shared by the whole grid and
-// claimed one at a time from `pool` (a device word that is 0 at launch; pool[1] counts finished workgroups,
-// and the last one to finish resets both for the next launch on the same stream).  pool == nullptr: no pool,
-// kstatic is unbounded and every chunk is static (small launches, launches under stream capture).
+// Work distribution of one launch (filled by the host, b2h_api.hip).
+//   pool == nullptr  STATIC: workgroup b (of G) owns the chunks b + G k and its waves draw them in order from a
+//                    counter in LDS (small launches, launches under stream capture);
+//   pool != nullptr  DYNAMIC: after a first deal (wave w of workgroup b: chunks (8 b + w) run .. + run - 1) every
+//                    wave claims RUNS of `run` consecutive chunks from `pool`, a device word that is 0 at launch:
+//                    a claim returns c, the run is chunks 8 G run + c .. + run - 1.  pool[1] counts finished
+//                    workgroups; the last one to finish resets both words for the next launch on the same stream.
 struct Sched16 {
     unsigned* pool;
-    unsigned kstatic;
+    unsigned run;
 };
 
 // STREAM: the launch is a stream (its rows are touched once and exceed the caches): non-temporal input loads
@@ -405,32 +407,39 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     // weights + biases of all four layers: one copy per workgroup
     for (int i = threadIdx.x; i < kPacked16 / 16; i += 64 * kWaves16)
         reinterpret_cast<uint4*>(smem16)[i] = reinterpret_cast<const uint4*>(wpacked)[i];
-    // Chunks are CLAIMED, not dealt.  (1) Inside a workgroup: its waves draw the workgroup's static chunks in
-    // order from a counter in LDS instead of each taking every eighth one.  The two waves of a SIMD do not run
-    // at the same speed -- the scheduler arbitrates by age, and tools/conv16_stamps.py shows waves 4-7 needing
-    // 1.55x the cycles of waves 0-3 per chunk -- so with a static split the older waves ran out of work at
-    // 77 % of the kernel and left each SIMD to one wave.  (2) Across workgroups: the XCDs do not run at the
-    // same speed either (workgroup end times differed by 7 %, by blockIdx % 8), so the last eighth of the
-    // launch is a pool that all workgroups draw from once their static share is gone.  A claim is made two
-    // chunks ahead (its answer is needed when the chunk after the next one is prefetched), so neither the LDS
-    // atomic nor the global one is ever waited for.  Which wave computes a chunk never changes its result.
+    // Chunks are CLAIMED, not dealt.  Round 3, in three steps:
+    // (1) the two waves of a SIMD do not run at the same speed -- the scheduler arbitrates by age, and
+    //     tools/conv16_stamps.py shows waves 4-7 needing 1.55x the cycles of waves 0-3 per chunk -- so with every
+    //     eighth chunk dealt to each wave the older waves ran out of work at 77 % of the kernel and left each SIMD
+    //     to one wave: the waves of a workgroup draw from a counter in LDS instead (STATIC launches still do);
+    // (2) the XCDs do not run at the same speed either (workgroup end times differed by 7 %, by blockIdx % 8);
+    // (3) and the memory system rewards a chip that walks through x and y as ONE tight front: the same bytes
+    //     stream 8 % faster through a non-persistent grid, whose workgroups the dispatcher hands out in order,
+    //     than through persistent workgroups with a fixed stride (tools/membench_sched.hip).  So large launches
+    //     are DYNAMIC: every wave claims runs of two consecutive chunks from one device-wide counter, in order --
+    //     runs of one make that counter the bottleneck (262 144 same-address atomics per launch: 3.1 ms), runs of
+    //     four already spread the front.  A claim is made two chunks ahead (its answer is needed when the chunk
+    //     after the next one is prefetched), so neither the LDS atomic nor the global one is ever waited for.
+    //     Which wave computes a chunk never changes its result.
     typedef __attribute__((address_space(3))) unsigned lds_u32;
     lds_u32* const queue = (lds_u32*)(smem16 + kLds16);
     if (threadIdx.x == 0) {
         queue[0] = 2 * kWaves16; // the first sixteen are dealt: wave w starts with chunks w and w + 8
-        queue[1] = 0;            // waves of this workgroup that are done (pool launches)
+        queue[1] = 0;            // waves of this workgroup that are done (dynamic launches)
     }
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     char* lds = smem16 + kPacked16 + wave * kWaveLds16;
-    const int64_t pool_base = (int64_t)gridDim.x * sched.kstatic; // first pool chunk (unused without a pool)
-    auto chunk_of = [&](unsigned k) { return blockIdx.x + (int64_t)gridDim.x * k; };
+    const bool dyn = sched.pool != nullptr; // (wave-uniform)
+    const int64_t pool_base = (int64_t)gridDim.x * kWaves16 * sched.run; // first claimed chunk (dynamic launches)
+    auto chunk_of = [&](unsigned k) { return blockIdx.x + (int64_t)gridDim.x * k; }; // static launches
     [[maybe_unused]] int64_t it = 0;   // chunks this wave has done (development stamps only)
-    int64_t chunk = chunk_of(wave);
-    if (chunk >= nchunks) return;     // (never with a pool: the host enables it for >= 64 chunks per workgroup)
-    int64_t next = chunk_of(wave + kWaves16);
+    int rem = (int)sched.run - 2;      // dynamic launches: chunks of the current run after `next` (run >= 2)
+    int64_t chunk = dyn ? ((int64_t)blockIdx.x * kWaves16 + wave) * sched.run : chunk_of(wave);
+    if (chunk >= nchunks) return;     // (never dynamic: the host asks for >= 256 chunks per workgroup there)
+    int64_t next = dyn ? chunk + 1 : chunk_of(wave + kWaves16);
     B2H_SPAN16(wave, lane, 0, __builtin_amdgcn_s_memrealtime());
 
     auto src_of = [&](const Geom16& gg) { return x + (gg.seq * (int64_t)T + gg.in_lo) * kInCh; };
@@ -451,20 +460,20 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     convert16<PREC, FUSED>(R, Q, src_of(g), g.nf4, lane, fu);
     while (true) {
         B2H_STAMP16(wave, lane, it, 0);
-        // claim the chunk after the next one: from the workgroup's share ...
+        // claim the chunk after the next one: static launches from the workgroup's share ...
         unsigned kn = 0;
-        if (lane == 0) kn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!dyn && lane == 0) kn = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         commit16<PREC>(Q, lds, g, T, lane, pos_emb);
         kn = __builtin_amdgcn_readfirstlane(kn);
-        // ... or, once that is used up, from the grid's pool.  The atomic is issued BEFORE the prefetch loads, so
+        // ... dynamic ones, when `next` ends its run, a new run from the device-wide counter.  The atomic is issued BEFORE the prefetch loads, so
         // the wait that the loads need anyway (pin_loads16, after layer 2) covers it: vmcnt counts in order.
         // (asm: hipcc's atomic optimizer wraps a __hip_atomic_fetch_add in a wave reduction whose readfirstlane
         // waits for the answer on the spot -- vmcnt(0) here, i.e. for every store of the previous chunk; for
         // the LDS claim above that wait is ~100 cycles and measured nothing)
-        const bool pooled = kn >= sched.kstatic;
+        const bool pooled = dyn && rem == 0;
         unsigned pv = 0;
         if (pooled && lane == 0)
-            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(pv) : "v"(0u), "v"(1u), "s"(sched.pool));
+            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(pv) : "v"(0u), "v"(sched.run), "s"(sched.pool));
         const bool more = next < nchunks;
         // prefetch the next chunk; unconditional (an empty buffer when nothing is left)
         // so that the register lifetimes below do not depend on control flow
@@ -489,7 +498,8 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
         // drains this chunk's 52 output stores.
         pin_loads16(R);
         asm volatile("" : "+v"(pv)); // the claim's answer is read after that wait, never before
-        const int64_t next2 = pooled ? pool_base + __builtin_amdgcn_readfirstlane(pv) : chunk_of(kn);
+        const int64_t next2 = pooled ? pool_base + __builtin_amdgcn_readfirstlane(pv) : dyn ? next + 1 : chunk_of(kn);
+        rem = pooled ? (int)sched.run - 1 : rem - 1;
         B2H_STAMP16(wave, lane, it, 5);
         convert16<PREC, FUSED>(R, Q, src_of(gn), nf4n, lane, fu);
         pin_regs16(Q);
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(64 * kWaves16, 2) void b2h_fwd_mfma16(
     }
     B2H_SPAN16(wave, lane, 1, __builtin_amdgcn_s_memrealtime());
     B2H_SPAN16(wave, lane, 2, (unsigned long long)(it + 1));
-    // Pool launches: the last wave of the last workgroup to finish leaves the pool words at 0 for the next
+    // Dynamic launches: the last wave of the last workgroup to finish leaves the pool words at 0 for the next
     // launch on this stream (every claim of every other wave has returned by then: a wave counts itself done
     // only after its last claim was consumed).
     if (sched.pool != nullptr && lane == 0) {

@@ -570,21 +570,21 @@ def test_error_vs_input_scale(cuda_device):
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 def test_claimed_chunks_pool_launches(prec, cuda_device):
-    """The persistent 16-bit kernel's work distribution (kernel_mfma16.h, Sched16): from 64 chunks per workgroup
-    on, the last eighth of a launch is a pool that every workgroup claims from, its counter in a per-stream
-    slot that the kernel itself leaves at zero.  Which wave computes a chunk must never show in the result:
-    a pool launch == the same sequences run in small launches (no pool, LDS queue only) == a launch captured
-    in a graph (no pool: a graph may replay on any stream), bit for bit; back-to-back pool launches on one
-    stream and concurrent ones on two streams (two slots) repeat it exactly."""
+    """The persistent 16-bit kernel's work distribution (kernel_mfma16.h, Sched16): from 256 chunks per workgroup
+    on a launch is DYNAMIC -- every wave claims runs of two consecutive chunks from a device-wide counter in a
+    per-stream slot that the kernel itself leaves at zero.  Which wave computes a chunk must never show in the
+    result: a dynamic launch == the same sequences run in small launches (static: LDS queue only) == a launch
+    captured in a graph (static: a graph may replay on any stream), bit for bit; back-to-back dynamic launches on
+    one stream and concurrent ones on two streams (two slots) repeat it exactly."""
     rec = load_golden("cfg2_b64_t200_u55")
     m = _model(rec, prec, cuda_device)
     ncu = torch.cuda.get_device_properties(cuda_device).multi_processor_count
-    S = 64 * ncu + 37                                  # >= 64 chunks per workgroup, not a multiple of anything
+    S = 256 * ncu + 37                                 # >= 256 chunks per workgroup, not a multiple of anything
     g = torch.Generator().manual_seed(33)
     x = (torch.rand((S, 200, 12, 2), generator=g) - 0.5).to(cuda_device)
     with torch.no_grad():
         y_pool = m(x)
-        y_small = torch.cat([m(x[a:a + 4000]) for a in range(0, S, 4000)])          # 15 chunks per workgroup: no pool
+        y_small = torch.cat([m(x[a:a + 4000]) for a in range(0, S, 4000)])          # 15 chunks per workgroup: static
         assert torch.equal(y_pool, y_small)
         idx = [0, 1, 4000, S - 1]
         ref = oracle.forward_from_state(x[idx].cpu().numpy(), rec["state"])

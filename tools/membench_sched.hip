@@ -109,7 +109,7 @@ __global__ void k_half(const char* __restrict__ x, char* __restrict__ y, int nse
 }
 
 // ---- roles: waves [0, R) read every sequence of the workgroup's share, waves [R, W) write them ----
-template <int R>
+template <int R, int LA = 0, int SA = 0>
 __global__ void k_roles(const char* __restrict__ x, char* __restrict__ y, int nseq, unsigned* sink) {
     const int W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -119,7 +119,7 @@ __global__ void k_roles(const char* __restrict__ x, char* __restrict__ y, int ns
             const __amdgpu_buffer_rsrc_t rs = rsrc(x + (size_t)seq * XB, XB);
             u32x4 v[19];
 #pragma unroll
-            for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0);
+            for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, LA);
 #pragma unroll
             for (int j = 0; j < 19; ++j) acc += v[j][0] ^ v[j][3];
         }
@@ -129,7 +129,7 @@ __global__ void k_roles(const char* __restrict__ x, char* __restrict__ y, int ns
             const __amdgpu_buffer_rsrc_t ws = rsrc(y + (size_t)seq * YB, YB);
             const u32x4 d = {acc, 2u, 3u, (unsigned)seq};
 #pragma unroll
-            for (int j = 0; j < 33; ++j) __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, 0);
+            for (int j = 0; j < 33; ++j) __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, SA);
         }
     }
     if (acc == 0x12345679u) sink[0] = acc;
@@ -175,7 +175,76 @@ __global__ void k_copy(const float4* __restrict__ x, float4* __restrict__ y, siz
 __global__ void k_copy_gs(const float4* __restrict__ x, float4* __restrict__ y, size_t n) { // grid stride, persistent
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i];
 }
+// ---- sync: persistent, but the workgroup's waves move in ROUNDS (a barrier per round): round k = the eight
+// ADJACENT sequences 8 (b + G k) .. + 7 (ADJ) or b + G (8k + wave) (far apart).  What the non-persistent form
+// does per workgroup, without its dispatch.  PREFETCH: next round's loads before this round's stores.
+template <bool PREFETCH, bool ADJ, int LA, int SA>
+__global__ void k_sync(const char* __restrict__ x, char* __restrict__ y, int nseq, unsigned* sink) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int rounds = nseq / (8 * (int)gridDim.x);
+    auto seq_of = [&](int k) { return ADJ ? 8 * ((int)blockIdx.x + (int)gridDim.x * k) + wave : (int)blockIdx.x + (int)gridDim.x * (8 * k + wave); };
+    unsigned acc = 0;
+    u32x4 v[19];
+    auto issue = [&](int k) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc(x + (size_t)seq_of(k < rounds ? k : 0) * XB, k < rounds ? XB : 0);
+#pragma unroll
+        for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, LA);
+    };
+    issue(0);
+    for (int k = 0; k < rounds; ++k) {
+#pragma unroll
+        for (int j = 0; j < 19; ++j) acc += v[j][0] ^ v[j][3];
+        __syncthreads();
+        if (PREFETCH) issue(k + 1);
+        const __amdgpu_buffer_rsrc_t ws = rsrc(y + (size_t)seq_of(k) * YB, YB);
+        const u32x4 d = {acc, 2u, 3u, (unsigned)k};
+#pragma unroll
+        for (int j = 0; j < 33; ++j) __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, SA);
+        if (!PREFETCH) issue(k + 1);
+    }
+    if (acc == 0x12345679u) sink[0] = acc;
+}
+
+// ---- dyn: persistent, every wave CLAIMS runs of RUN consecutive sequences from one global counter (claimed one run
+// ahead, so the atomic's latency is never waited for): the in-order dynamic dispatch of the non-persistent form,
+// inside a persistent kernel.
+template <int RUN, int LA, int SA>
+__global__ void k_dyn(const char* __restrict__ x, char* __restrict__ y, int nseq, unsigned* sink, unsigned* counter) {
+    const int lane = threadIdx.x & 63;
+    unsigned acc = 0;
+    u32x4 v[19];
+    auto claim = [&]() {
+        unsigned c = 0;
+        if (lane == 0) c = atomicAdd(counter, (unsigned)RUN);
+        return (int)__builtin_amdgcn_readfirstlane(c);
+    };
+    auto issue = [&](int sq) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc(x + (size_t)(sq < nseq ? sq : 0) * XB, sq < nseq ? XB : 0);
+#pragma unroll
+        for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, LA);
+    };
+    int cur = claim(), nxt = claim();
+    issue(cur);
+    while (cur < nseq) {
+        for (int r = 0; r < RUN; ++r) {
+            const int sq = cur + r;
+            if (sq >= nseq) break;
+#pragma unroll
+            for (int j = 0; j < 19; ++j) acc += v[j][0] ^ v[j][3];
+            issue(r + 1 < RUN ? sq + 1 : nxt); // prefetch: next sequence of the run, or the first of the next run
+            const __amdgpu_buffer_rsrc_t ws = rsrc(y + (size_t)sq * YB, YB);
+            const u32x4 d = {acc, 2u, 3u, (unsigned)sq};
+#pragma unroll
+            for (int j = 0; j < 33; ++j) __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, SA);
+        }
+        cur = nxt;
+        nxt = claim();
+    }
+    if (acc == 0x12345679u) sink[0] = acc;
+}
+
 // non-persistent seq kernel: one wave per sequence, the dispatcher hands workgroups out in order
+template <int LA = 0, int SA = 0>
 __global__ void k_seq_np(const char* __restrict__ x, char* __restrict__ y, int nseq, unsigned* sink) {
     const int W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -185,13 +254,13 @@ __global__ void k_seq_np(const char* __restrict__ x, char* __restrict__ y, int n
     u32x4 v[19];
     unsigned acc = 0;
 #pragma unroll
-    for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 0);
+    for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, LA);
 #pragma unroll
     for (int j = 0; j < 19; ++j) acc += v[j][0] ^ v[j][3];
     const __amdgpu_buffer_rsrc_t ws = rsrc(y + (size_t)seq * YB, YB);
     const u32x4 d = {acc, 2u, 3u, (unsigned)seq};
 #pragma unroll
-    for (int j = 0; j < 33; ++j) __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, 0);
+    for (int j = 0; j < 33; ++j) __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, SA);
     if (acc == 0x12345679u) sink[0] = acc;
 }
 
@@ -231,6 +300,29 @@ int main(int argc, char** argv) {
             run("half W=12 6 x 3 sleep 10, loads nt stores nt sc1", bytes, L((k_half<6, 10, 2, 18>), 12));
             run("base W=4 prefetch, loads nt stores nt sc1", bytes, L((k_trickle<1, 0, true, 2, 18>), 4));
             run("base W=16 prefetch, loads nt stores nt sc1", bytes, L((k_trickle<1, 0, true, 2, 18>), 16));
+            run("non-persistent 8 waves/wg, loads 0 stores 0", bytes, [&] { hipLaunchKernelGGL((k_seq_np<0, 0>), dim3(nseq / 8), dim3(512), 0, 0, x, y, nseq, sink); });
+            run("non-persistent 8 waves/wg, loads nt stores nt sc1", bytes, [&] { hipLaunchKernelGGL((k_seq_np<2, 18>), dim3(nseq / 8), dim3(512), 0, 0, x, y, nseq, sink); });
+            // the same with the real kernel's occupancy: 160 KB of dynamic LDS per 8-wave workgroup = one workgroup per CU
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seq_np<2, 18>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seq_np<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            run("non-persistent 8 waves/wg, ONE workgroup per CU (160 KB LDS), loads 0 stores 0", bytes, [&] { hipLaunchKernelGGL((k_seq_np<0, 0>), dim3(nseq / 8), dim3(512), 160 * 1024, 0, x, y, nseq, sink); });
+            run("non-persistent 8 waves/wg, ONE workgroup per CU (160 KB LDS), nt / nt sc1", bytes, [&] { hipLaunchKernelGGL((k_seq_np<2, 18>), dim3(nseq / 8), dim3(512), 160 * 1024, 0, x, y, nseq, sink); });
+            run("non-persistent 8 waves/wg, TWO workgroups per CU (80 KB LDS), nt / nt sc1", bytes, [&] { hipLaunchKernelGGL((k_seq_np<2, 18>), dim3(nseq / 8), dim3(512), 80 * 1024, 0, x, y, nseq, sink); });
+#define LD(K) [&] { CK(hipMemsetAsync(t0, 0, 8, 0)); hipLaunchKernelGGL(K, dim3(256), dim3(512), 0, 0, x, y, nseq, sink, (unsigned*)t0); }
+            run("dyn claims, runs of 1, nt / nt sc1", bytes, LD((k_dyn<1, 2, 18>)));
+            run("dyn claims, runs of 2, nt / nt sc1", bytes, LD((k_dyn<2, 2, 18>)));
+            run("dyn claims, runs of 4, nt / nt sc1", bytes, LD((k_dyn<4, 2, 18>)));
+            run("dyn claims, runs of 8, nt / nt sc1", bytes, LD((k_dyn<8, 2, 18>)));
+            run("dyn claims, runs of 16, nt / nt sc1", bytes, LD((k_dyn<16, 2, 18>)));
+            run("dyn claims, runs of 4, default policy", bytes, LD((k_dyn<4, 0, 0>)));
+            run("sync rounds, adjacent, no prefetch, nt / nt sc1", bytes, L((k_sync<false, true, 2, 18>), 8));
+            run("sync rounds, adjacent, prefetch, nt / nt sc1", bytes, L((k_sync<true, true, 2, 18>), 8));
+            run("sync rounds, far apart, no prefetch, nt / nt sc1", bytes, L((k_sync<false, false, 2, 18>), 8));
+            run("sync rounds, far apart, prefetch, nt / nt sc1", bytes, L((k_sync<true, false, 2, 18>), 8));
+            run("sync rounds, adjacent, no prefetch, default policy", bytes, L((k_sync<false, true, 0, 0>), 8));
+            run("roles W=8 4 + 4, loads 0 stores 0", bytes, L((k_roles<4, 0, 0>), 8));
+            run("roles W=8 4 + 4, loads nt stores nt sc1", bytes, L((k_roles<4, 2, 18>), 8));
+            run("roles W=8 7 + 1, loads nt stores nt sc1", bytes, L((k_roles<7, 2, 18>), 8));
         }
         return 0;
     }
@@ -262,8 +354,8 @@ int main(int argc, char** argv) {
                     hipLaunchKernelGGL(k_phased, dim3(256), dim3(512), 0, 0, x, y, nseq, sink, t0, P, RD);
                 });
             }
-        run("non-persistent, 8 waves per workgroup", bytes, [&] { hipLaunchKernelGGL(k_seq_np, dim3(nseq / 8), dim3(512), 0, 0, x, y, nseq, sink); });
-        run("non-persistent, 4 waves per workgroup", bytes, [&] { hipLaunchKernelGGL(k_seq_np, dim3(nseq / 4), dim3(256), 0, 0, x, y, nseq, sink); });
+        run("non-persistent, 8 waves per workgroup", bytes, [&] { hipLaunchKernelGGL((k_seq_np<0, 0>), dim3(nseq / 8), dim3(512), 0, 0, x, y, nseq, sink); });
+        run("non-persistent, 4 waves per workgroup", bytes, [&] { hipLaunchKernelGGL((k_seq_np<0, 0>), dim3(nseq / 4), dim3(256), 0, 0, x, y, nseq, sink); });
         {
             const size_t n = (size_t)nseq * XB / 16; // copy the input buffer's size into y: 2 x 5.03 GB
             run("float4 copy, 256-thread blocks, one element per thread", 2.0 * n * 16,
