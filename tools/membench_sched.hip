@@ -208,7 +208,7 @@ __global__ void k_sync(const char* __restrict__ x, char* __restrict__ y, int nse
 // ---- dyn: persistent, every wave CLAIMS runs of RUN consecutive sequences from one global counter (claimed one run
 // ahead, so the atomic's latency is never waited for): the in-order dynamic dispatch of the non-persistent form,
 // inside a persistent kernel.
-template <int RUN, int LA, int SA>
+template <int RUN, int LA, int SA, int GROUPS = 1, int SLEEP = 0> // GROUPS / SLEEP: the stores trickle like the head layer's
 __global__ void k_dyn(const char* __restrict__ x, char* __restrict__ y, int nseq, unsigned* sink, unsigned* counter) {
     const int lane = threadIdx.x & 63;
     unsigned acc = 0;
@@ -234,8 +234,14 @@ __global__ void k_dyn(const char* __restrict__ x, char* __restrict__ y, int nseq
             issue(r + 1 < RUN ? sq + 1 : nxt); // prefetch: next sequence of the run, or the first of the next run
             const __amdgpu_buffer_rsrc_t ws = rsrc(y + (size_t)sq * YB, YB);
             const u32x4 d = {acc, 2u, 3u, (unsigned)sq};
+            constexpr int PER = (33 + GROUPS - 1) / GROUPS;
 #pragma unroll
-            for (int j = 0; j < 33; ++j) __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, SA);
+            for (int gq = 0; gq < GROUPS; ++gq) {
+#pragma unroll
+                for (int j = gq * PER; j < (gq + 1) * PER && j < 33; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(d, ws, lane * 16, j * 1024, SA);
+                if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+            }
         }
         cur = nxt;
         nxt = claim();
@@ -315,6 +321,10 @@ int main(int argc, char** argv) {
             run("dyn claims, runs of 8, nt / nt sc1", bytes, LD((k_dyn<8, 2, 18>)));
             run("dyn claims, runs of 16, nt / nt sc1", bytes, LD((k_dyn<16, 2, 18>)));
             run("dyn claims, runs of 4, default policy", bytes, LD((k_dyn<4, 0, 0>)));
+            run("dyn claims, runs of 2, stores 11 x 3 sleep 8", bytes, LD((k_dyn<2, 2, 18, 11, 8>)));
+            run("dyn claims, runs of 2, stores 11 x 3 sleep 16", bytes, LD((k_dyn<2, 2, 18, 11, 16>)));
+            run("dyn claims, runs of 2, stores 11 x 3 sleep 32", bytes, LD((k_dyn<2, 2, 18, 11, 32>)));
+            run("dyn claims, runs of 2, stores 3 x 11 sleep 32", bytes, LD((k_dyn<2, 2, 18, 3, 32>)));
             run("sync rounds, adjacent, no prefetch, nt / nt sc1", bytes, L((k_sync<false, true, 2, 18>), 8));
             run("sync rounds, adjacent, prefetch, nt / nt sc1", bytes, L((k_sync<true, true, 2, 18>), 8));
             run("sync rounds, far apart, no prefetch, nt / nt sc1", bytes, L((k_sync<false, false, 2, 18>), 8));
