@@ -482,6 +482,28 @@ def test_adaptive_chunk_lengths_are_bit_identical(prec, cuda_device):
     assert np.abs(y_small.cpu().numpy() - ref).max() <= TOL[prec]
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_dynamic_launch_with_chunked_sequences(prec, cuda_device):
+    """A DYNAMIC launch (>= 256 chunks per workgroup) of sequences longer than one chunk (T = 400: three chunks
+    of <= 192 frames with halos): a claimed run of two consecutive chunks then straddles sequences.  Must equal
+    the same sequences run in small static launches, bit for bit, and the oracle on a sample."""
+    rec = load_golden("cfg2_b64_t200_u55")
+    m = _model(rec, prec, cuda_device)
+    ncu = torch.cuda.get_device_properties(cuda_device).multi_processor_count
+    T = 400
+    S = (256 * ncu + 2) // 3 + 11                      # 3 chunks per sequence -> a little over 256 per workgroup
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand((S, T, 12, 2), generator=g) - 0.5).to(cuda_device)
+    with torch.no_grad():
+        y = m(x)
+        y_small = torch.cat([m(x[a:a + 1000]) for a in range(0, S, 1000)])
+        assert torch.equal(y, y_small)
+        assert torch.equal(m(x), y)                                      # the counter is back at zero
+        idx = [0, 999, 1000, S - 1]
+        ref = oracle.forward_from_state(x[idx].cpu().numpy(), rec["state"])
+        assert np.abs(y[idx].cpu().numpy() - ref).max() <= TOL[prec]
+
+
 @pytest.mark.parametrize("prec", ALL_PREC)
 def test_fused_every_length(prec, cuda_device):
     """The fused instantiation against the plain kernel of the same precision at EVERY length 1..80

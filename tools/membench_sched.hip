@@ -325,6 +325,10 @@ int main(int argc, char** argv) {
             run("dyn claims, runs of 2, stores 11 x 3 sleep 16", bytes, LD((k_dyn<2, 2, 18, 11, 16>)));
             run("dyn claims, runs of 2, stores 11 x 3 sleep 32", bytes, LD((k_dyn<2, 2, 18, 11, 32>)));
             run("dyn claims, runs of 2, stores 3 x 11 sleep 32", bytes, LD((k_dyn<2, 2, 18, 3, 32>)));
+            run("dyn claims, runs of 2, stores 6 x 6 sleep 16", bytes, LD((k_dyn<2, 2, 18, 6, 16>)));
+            run("dyn claims, runs of 2, stores 6 x 6 sleep 32", bytes, LD((k_dyn<2, 2, 18, 6, 32>)));
+            run("dyn claims, runs of 2, stores 8 x 5 sleep 16", bytes, LD((k_dyn<2, 2, 18, 8, 16>)));
+            run("dyn claims, runs of 2, stores 2 x 17 sleep 64", bytes, LD((k_dyn<2, 2, 18, 2, 64>)));
             run("sync rounds, adjacent, no prefetch, nt / nt sc1", bytes, L((k_sync<false, true, 2, 18>), 8));
             run("sync rounds, adjacent, prefetch, nt / nt sc1", bytes, L((k_sync<true, true, 2, 18>), 8));
             run("sync rounds, far apart, no prefetch, nt / nt sc1", bytes, L((k_sync<false, false, 2, 18>), 8));
