@@ -249,6 +249,58 @@ __global__ void k_dyn(const char* __restrict__ x, char* __restrict__ y, int nseq
     if (acc == 0x12345679u) sink[0] = acc;
 }
 
+// ---- dyn + scratch: the head layer's trickle goes to a per-wave scratch (33.6 KB each, reused every sequence, so it
+// should stay in L2 / Infinity Cache), and the sequence's rows then leave for y as ONE burst read back from there.
+template <int SLEEP, int SCR_ST, int SCR_LD>
+__global__ void k_dyn_scratch(const char* __restrict__ x, char* __restrict__ y, int nseq, unsigned* sink, unsigned* counter,
+                              char* __restrict__ scratch) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const __amdgpu_buffer_rsrc_t ss = rsrc(scratch + (size_t)gw * (34 * 1024), 34 * 1024);
+    unsigned acc = 0;
+    u32x4 v[19];
+    auto claim = [&]() {
+        unsigned c = 0;
+        if (lane == 0) c = atomicAdd(counter, 2u);
+        return (int)__builtin_amdgcn_readfirstlane(c);
+    };
+    auto issue = [&](int sq) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc(x + (size_t)(sq < nseq ? sq : 0) * XB, sq < nseq ? XB : 0);
+#pragma unroll
+        for (int j = 0; j < 19; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, j * 1024, 2);
+    };
+    int cur = claim(), nxt = claim();
+    issue(cur);
+    while (cur < nseq) {
+        for (int r = 0; r < 2; ++r) {
+            const int sq = cur + r;
+            if (sq >= nseq) break;
+#pragma unroll
+            for (int j = 0; j < 19; ++j) acc += v[j][0] ^ v[j][3];
+            issue(r == 0 ? sq + 1 : nxt);
+            const u32x4 d = {acc, 2u, 3u, (unsigned)sq};
+#pragma unroll
+            for (int gq = 0; gq < 11; ++gq) { // the trickle, into the scratch
+#pragma unroll
+                for (int j = gq * 3; j < gq * 3 + 3; ++j) __builtin_amdgcn_raw_buffer_store_b128(d, ss, lane * 16, j * 1024, SCR_ST);
+                if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+            }
+            const __amdgpu_buffer_rsrc_t ws = rsrc(y + (size_t)sq * YB, YB);
+#pragma unroll
+            for (int h = 0; h < 3; ++h) { // the burst: 11 rows at a time through registers
+                u32x4 t[11];
+#pragma unroll
+                for (int j = 0; j < 11; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b128(ss, lane * 16, (h * 11 + j) * 1024, SCR_LD);
+#pragma unroll
+                for (int j = 0; j < 11; ++j) __builtin_amdgcn_raw_buffer_store_b128(t[j], ws, lane * 16, (h * 11 + j) * 1024, 18);
+            }
+        }
+        cur = nxt;
+        nxt = claim();
+    }
+    if (acc == 0x12345679u) sink[0] = acc;
+}
+
 // non-persistent seq kernel: one wave per sequence, the dispatcher hands workgroups out in order
 template <int LA = 0, int SA = 0>
 __global__ void k_seq_np(const char* __restrict__ x, char* __restrict__ y, int nseq, unsigned* sink) {
@@ -325,6 +377,14 @@ int main(int argc, char** argv) {
             run("dyn claims, runs of 2, stores 11 x 3 sleep 16", bytes, LD((k_dyn<2, 2, 18, 11, 16>)));
             run("dyn claims, runs of 2, stores 11 x 3 sleep 32", bytes, LD((k_dyn<2, 2, 18, 11, 32>)));
             run("dyn claims, runs of 2, stores 3 x 11 sleep 32", bytes, LD((k_dyn<2, 2, 18, 3, 32>)));
+            {
+                char* scratch; CK(hipMalloc(&scratch, (size_t)2048 * 34 * 1024)); CK(hipMemset(scratch, 0, (size_t)2048 * 34 * 1024));
+#define LDS_(K) [&] { CK(hipMemsetAsync(t0, 0, 8, 0)); hipLaunchKernelGGL(K, dim3(256), dim3(512), 0, 0, x, y, nseq, sink, (unsigned*)t0, scratch); }
+                run("dyn 2 + scratch: trickle (sleep 16) to scratch default, burst to y", bytes, LDS_((k_dyn_scratch<16, 0, 0>)));
+                run("dyn 2 + scratch: trickle (sleep 16) to scratch sc0, burst loads sc0", bytes, LDS_((k_dyn_scratch<16, 1, 1>)));
+                run("dyn 2 + scratch: no sleep, scratch default", bytes, LDS_((k_dyn_scratch<0, 0, 0>)));
+                CK(hipFree(scratch));
+            }
             run("dyn claims, runs of 2, stores 6 x 6 sleep 16", bytes, LD((k_dyn<2, 2, 18, 6, 16>)));
             run("dyn claims, runs of 2, stores 6 x 6 sleep 32", bytes, LD((k_dyn<2, 2, 18, 6, 32>)));
             run("dyn claims, runs of 2, stores 8 x 5 sleep 16", bytes, LD((k_dyn<2, 2, 18, 8, 16>)));
